@@ -1,0 +1,177 @@
+/*
+ * srt_pathtrace.h — C-ABI of the MI355X path-trace library (libsrt_pathtrace.so).
+ *
+ * This is the drop-in boundary for ONE hot path of JoshuaLim007/Software-Raytracer:
+ * the per-pixel trace / shade / accumulate loop.  The reference has no plugin or
+ * FFI interface; the seam this ABI replaces is the tile worker
+ *
+ *     void renderArea(unsigned index, unsigned minX, unsigned maxX,
+ *                     unsigned minY, unsigned maxY, const Transform* camera)
+ *                                                  (Raytracer/Raytracer.cpp:223-257)
+ *
+ * together with the globals that worker reads (Raytracer.cpp:30-35,46-48,55-61) and
+ * the two buffers it writes (colorBuffer :60, renderSurface->pixels :50,64).
+ * Every entry point below names the reference state it stands for.
+ *
+ * Conventions
+ *   - plain C, POD structs, caller-owned host memory; no pointer is retained after a
+ *     call returns (srt_set_scene copies).
+ *   - every function returns an srt_status (0 = ok); srt_last_error() gives text.
+ *     Nothing throws or aborts across the boundary.
+ *   - a handle is single-owner and not re-entrant; independent handles (one per GPU)
+ *     may be used from independent threads.
+ *   - srt_render is asynchronous on the handle's HIP stream; srt_wait / srt_poll
+ *     stand for the reference's threadGroupStatus[] scan (Raytracer.cpp:373-384).
+ *   - there is NO CPU fallback: without a HIP device srt_create fails with
+ *     SRT_ERR_NO_DEVICE.
+ *
+ * Framebuffer contract (Raytracer.cpp:64, Common.hpp:189-208):
+ *   uint32 per pixel = A<<24 | R<<16 | G<<8 | B  (A is always 0), rows bottom-up:
+ *   scene pixel (x, y) lives in memory row H-1-y.  "Memory rows" below always mean
+ *   rows of that flipped image; the float4 accumulator is indexed x + y*W with the
+ *   scene row y (Raytracer.cpp:67), exactly as colorBuffer is.
+ */
+#ifndef SRT_PATHTRACE_H
+#define SRT_PATHTRACE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRT_ABI_VERSION 1
+
+typedef enum srt_status {
+    SRT_OK = 0,
+    SRT_ERR_INVALID_ARG = 1,
+    SRT_ERR_NO_DEVICE = 2,   /* no HIP device / HIP runtime unusable: there is no CPU fallback */
+    SRT_ERR_HIP = 3,         /* a HIP call failed; text in srt_last_error */
+    SRT_ERR_STATE = 4,       /* call order violated (e.g. render before set_scene / set_camera) */
+    SRT_ERR_OOM = 5
+} srt_status;
+
+/* Object kinds the reference loader knows (Raytracer/Scene.hpp:43-55). */
+typedef enum srt_object_type {
+    SRT_OBJ_NONE = 0,    /* inert Object: occupies a list slot, never hit (Object.hpp:21-23) */
+    SRT_OBJ_SPHERE = 1,  /* Sphere (Object.hpp:86-168): uses position + radius          */
+    SRT_OBJ_BOX = 2      /* Box    (Object.hpp:170-234): axis-aligned, half_size = Box::size */
+} srt_object_type;
+
+/* Material (Raytracer/Common.hpp:293-319), 11 floats. Colours are the r,g,b of the
+ * reference's Color (its a is always 0 on this path). */
+typedef struct srt_material {
+    float smoothness;
+    float specular_amount;
+    float base_color[3];
+    float emissive_color[3];
+    float specular_color[3];
+} srt_material;
+
+/* One element of ObjectsToRender (Raytracer.cpp:61), flattened. List order is kept:
+ * the closest-hit scan keeps the lower index on equal distances (Raytracer.cpp:132). */
+typedef struct srt_object {
+    int32_t type;        /* srt_object_type */
+    float position[3];   /* transform.position */
+    float radius;        /* Sphere::radius (transform.scale is NOT used by the intersector) */
+    float half_size[3];  /* Box::size, half extents */
+    srt_material material;
+} srt_object;
+
+/* Environment globals (Raytracer.cpp:55-59). sun_direction is the already normalised
+ * vector (the reference normalises once at start-up, :264). */
+typedef struct srt_environment {
+    float sun_direction[3];
+    float sky_color[3];
+    float horizon_color[3];
+    float ground_color[3];
+    float sun_color[3];
+} srt_environment;
+
+/* Camera = the reference's Transform (Common.hpp:281-292) + the FOV global (:31).
+ * FOV is an integer number of degrees, vertical, exactly as in Raytracer.cpp:112. */
+typedef struct srt_camera {
+    float position[3];
+    float right[3];
+    float up[3];
+    float forward[3];
+    int32_t fov_degrees;
+} srt_camera;
+
+#define SRT_RENDER_RESET 1u       /* first sample of this call overwrites (setFrame, :69-71) */
+#define SRT_RENDER_COUNT_RAYS 2u  /* fill srt_stats.rays (costs one atomic per wave)       */
+
+/* One render call = sample_count successive "frames" of the reference's loop over a
+ * band of memory rows, all on the device, accumulator kept in registers in between.
+ *   sample f (1-based, = ACCUMULATIONFRAMES) keys the RNG and sets the running-mean
+ *   weight w = (float)(1.0 / f)               (Raytracer.cpp:66-67).
+ *   Clean sequence: first_sample = 1 with SRT_RENDER_RESET, later calls continue with
+ *   first_sample = previous + count and no reset. */
+typedef struct srt_render_params {
+    int32_t row_begin;      /* first memory row (inclusive), 0 = top line of the blitted image */
+    int32_t row_end;        /* one past the last memory row */
+    uint32_t first_sample;  /* >= 1 */
+    uint32_t sample_count;  /* >= 1 */
+    int32_t max_bounces;    /* MAXBOUNCES (Raytracer.cpp:32), >= 0 */
+    uint32_t seed;          /* RNG seed; the reference names only srand(0) (:263) */
+    uint32_t flags;         /* SRT_RENDER_* */
+} srt_render_params;
+
+typedef struct srt_stats {
+    uint64_t rays;          /* GetClosestObject calls (primary counted once per sample) */
+    uint64_t path_samples;  /* W_band * H_band * sample_count of the last render */
+    float kernel_ms;        /* HIP-event time of the last render's kernel on its stream */
+} srt_stats;
+
+typedef struct srt_context srt_context;
+
+/* ---- lifetime ------------------------------------------------------------------ */
+int srt_abi_version(void);
+/* Number of HIP devices visible; *count = 0 and SRT_ERR_NO_DEVICE when none. */
+int srt_device_count(int* count);
+/* width/height replace SCREEN_WIDTH / SCREEN_HEIGHT (Raytracer.cpp:26-27) at run time. */
+int srt_create(int device, int width, int height, srt_context** out);
+int srt_destroy(srt_context* ctx);
+/* Text of the last failure on ctx (ctx may be NULL: last srt_create failure of this thread). */
+const char* srt_last_error(const srt_context* ctx);
+
+/* ---- state the worker reads ---------------------------------------------------- */
+/* Replaces ObjectsToRender (Raytracer.cpp:61,293). Copies; count may be 0. */
+int srt_set_scene(srt_context* ctx, const srt_object* objects, size_t count);
+/* Replaces SunDirection/SkyColor/HorizonColor/GroundColor/SunColor (:55-59). */
+int srt_set_environment(srt_context* ctx, const srt_environment* env);
+/* Fills env with the reference's start-up values, computed the way :55-59,264 do. */
+int srt_environment_default(srt_environment* env);
+/* Replaces the `camera` Transform handed to renderArea (:227,295-297) and FOV (:31). */
+int srt_set_camera(srt_context* ctx, const srt_camera* camera);
+
+/* ---- optional device-side plumbing --------------------------------------------- */
+/* Launch on this hipStream_t instead of the handle's own stream (NULL = own stream). */
+int srt_set_stream(srt_context* ctx, void* hip_stream);
+/* Render into caller-provided DEVICE buffers (e.g. a torch tensor's data_ptr) instead of
+ * the handle's own: framebuffer = W*H uint32, accumulator = W*H float4. NULL = own. */
+int srt_bind_output(srt_context* ctx, void* d_framebuffer, void* d_accumulator);
+int srt_device_framebuffer(srt_context* ctx, void** d_ptr);
+int srt_device_accumulator(srt_context* ctx, void** d_ptr);
+
+/* ---- the hot path -------------------------------------------------------------- */
+/* Replaces one release of the workers (threadGroupStatus[i] = false, :592-595) for
+ * sample_count frames. Asynchronous. */
+int srt_render(srt_context* ctx, const srt_render_params* params);
+int srt_wait(srt_context* ctx);             /* block until the last render finished */
+int srt_poll(srt_context* ctx, int* done);  /* *done = 1 when finished              */
+int srt_get_stats(srt_context* ctx, srt_stats* out);  /* waits for the last render */
+
+/* ---- buffers the worker writes ------------------------------------------------- */
+/* Copies memory rows [row_begin,row_end) into dst (dst points at row_begin's first
+ * pixel), pitch_bytes per row (>= 4*W) — the renderSurface->pixels layout (:64). Waits. */
+int srt_read_framebuffer(srt_context* ctx, void* dst, size_t pitch_bytes, int row_begin, int row_end);
+/* colorBuffer (:60): W*H float4 (r,g,b,a), index x + y*W, scene rows. Wait + copy. */
+int srt_read_accumulator(srt_context* ctx, float* dst_rgba);
+int srt_write_accumulator(srt_context* ctx, const float* src_rgba);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRT_PATHTRACE_H */
