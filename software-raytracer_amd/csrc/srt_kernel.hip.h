@@ -1,0 +1,416 @@
+// srt_kernel.hip.h — gfx950 (CDNA4) path-trace kernel: one work-item = one pixel.
+//
+// What it computes is, bit for bit, the reference's per-pixel loop
+//   GetRayDirection -> RaytraceScene -> SetScreenPixel   (Raytracer/Raytracer.cpp:63-213)
+// with Object.hpp's Sphere / Box intersectors and Common.hpp's float3 / Color value
+// semantics, for `sample_count` successive frames in one launch.  HOW it computes it is
+// MI355X-first and shares nothing with the reference's structure:
+//
+//   * wavefront (64 lanes) = 8x8 pixel tile; workgroup = 4 waves = 16x16 pixels.
+//   * the flattened scene (spheres as (c.xyz, r^2) float4, boxes as two float4, a
+//     48-byte material row per primitive) is staged ONCE per workgroup into LDS; in the
+//     closest-hit scan every lane reads the same LDS address (ds_read_b128 broadcast,
+//     conflict-free), so the scan is pure VALU.
+//   * the scan keeps only (best distance, primitive id); the expensive hit record
+//     (sqrt, point, normal) is computed under a __ballot-uniform branch only when some
+//     lane of the wave passes the cheap d2 <= r^2 test, and the normal/point only once
+//     for the winner after the scan.
+//   * primary rays do not depend on the sample (no jitter, Raytracer.cpp:109-110), so
+//     the primary hit is found once per pixel and reused by every sample.
+//   * per-lane path regeneration: a lane whose path ended accumulates its sample and
+//     immediately starts the next one, so the wave loops max_lane(sum of rays) times,
+//     not sum_samples(max_lane(rays)).
+//   * the accumulator (running mean, Raytracer.cpp:65-71) lives in registers for the
+//     whole launch: one 16-byte accumulator store + one 4-byte ARGB store per pixel.
+//   * counter-based RNG keyed (seed, absolute pixel, sample, draw#): include/srt_defs.h.
+//
+// Bit-exactness rules (the file is compiled with -ffp-contract=off; hipcc's default
+// correctly-rounded fp32 divide/sqrt stays on; fp32 denormals are not flushed):
+//   every expression keeps the reference's association; Color results go through
+//   clamp0() like Color's constructor (Common.hpp:253-262); comparisons keep their NaN
+//   behaviour (a > b ? a : b, never fmaxf).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "srt_defs.h"
+
+namespace srt {
+
+// ---- device scene image (identical bytes in HBM and in LDS) ----------------------
+// float4 units:  [0 .. ns)                      sphere  (cx, cy, cz, r*r)
+//                [ns .. ns+2nb)                 box     (cx, cy, cz, _), (hx, hy, hz, _)
+//                [ns+2nb .. ns+2nb+3(ns+nb))    material rows, primitive order:
+//                     (smoothness, specular_amount, base.r, base.g)
+//                     (base.b, emissive.r, emissive.g, emissive.b)
+//                     (specular.r, specular.g, specular.b, bits(list index))
+// primitive id p: spheres 0..ns-1 in list order, then boxes ns..ns+nb-1 in list order.
+struct KernelParams {
+    float cam_pos[3];
+    float right_rd[3];  // cameraTransform.right * rd          (Raytracer.cpp:114,116)
+    float up_ld[3];     // cameraTransform.up * ld             (:115,117)
+    float fwd_clip[3];  // cameraTransform.forward * clipDist  (:113)
+    float sun_dir[3];
+    float sky[3], horizon[3], ground[3], sun[3];
+    int32_t width, height;
+    int32_t y0, rows;  // scene rows [y0, y0+rows)
+    uint32_t first_sample, sample_count;
+    int32_t max_bounces;
+    uint32_t seed, flags;
+    int32_t ns, nb;
+    int32_t scene_vec4;  // number of float4 in the scene image
+    const float4* scene;
+    float4* accumulator;
+    uint32_t* framebuffer;
+    unsigned long long* ray_counter;
+};
+
+constexpr int TILE_W = 8, TILE_H = 8;       // per wavefront
+constexpr int WG_TILES_X = 2, WG_TILES_Y = 2;  // waves per workgroup
+constexpr int WG_THREADS = 64 * WG_TILES_X * WG_TILES_Y;
+constexpr int WG_W = TILE_W * WG_TILES_X, WG_H = TILE_H * WG_TILES_Y;
+
+__device__ __forceinline__ float clamp0(float v) { return v < 0 ? 0.0f : v; }  // Common.hpp:254-257
+
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+// float3::Normalized (Common.hpp:159-162)
+__device__ __forceinline__ V3 normalized(V3 a) {
+    float length = sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z);
+    return v3(a.x / length, a.y / length, a.z / length);
+}
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+
+struct Lds {
+    const float4* v;  // LDS base
+    int ns, nb;
+    __device__ __forceinline__ float4 sphere(int j) const { return v[j]; }
+    __device__ __forceinline__ float4 box_c(int j) const { return v[ns + 2 * j]; }
+    __device__ __forceinline__ float4 box_h(int j) const { return v[ns + 2 * j + 1]; }
+    __device__ __forceinline__ float4 mat(int p, int row) const { return v[ns + 2 * nb + 3 * p + row]; }
+};
+
+// sign(float3) component (Common.hpp:328-333): t != 0 ? t / abs(t) : 0
+__device__ __forceinline__ float sign1(float t) { return t != 0 ? t / fabsf(t) : 0.0f; }
+// template max / min (Common.hpp:344-351)
+__device__ __forceinline__ float tmax(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ float tmin(float a, float b) { return a < b ? a : b; }
+
+struct BoxRay {  // per-ray part of Box::iBox (Object.hpp:175): depends on rd only
+    V3 sgn, m, am;
+};
+__device__ __forceinline__ BoxRay box_ray_setup(V3 rd) {
+    BoxRay b;
+    b.sgn = v3(sign1(rd.x), sign1(rd.y), sign1(rd.z));
+    const float eps = (float)1e-8;
+    b.m = v3(b.sgn.x / tmax(fabsf(rd.x), eps), b.sgn.y / tmax(fabsf(rd.y), eps), b.sgn.z / tmax(fabsf(rd.z), eps));
+    b.am = v3(fabsf(b.m.x), fabsf(b.m.y), fabsf(b.m.z));
+    return b;
+}
+// Box::iBox (Object.hpp:173-200) distance part; t1 out for the normal.
+__device__ __forceinline__ float ibox_dist(const BoxRay& br, V3 ro, V3 size, V3& t1) {
+    V3 n = v3(br.m.x * ro.x, br.m.y * ro.y, br.m.z * ro.z);
+    V3 k = v3(br.am.x * size.x, br.am.y * size.y, br.am.z * size.z);
+    t1 = v3(n.x * -1 - k.x, n.y * -1 - k.y, n.z * -1 - k.z);
+    V3 t2 = v3(n.x * -1 + k.x, n.y * -1 + k.y, n.z * -1 + k.z);
+    float tN = tmax(tmax(t1.x, t1.y), t1.z);
+    float tF = tmin(tmin(t2.x, t2.y), t2.z);
+    const float FMAX = 3.402823466e+38f;
+    if (tN > tF || tF <= 0.0f) return FMAX;
+    if (tN >= (float)0.01 && tN <= 10000.0f) return tN;
+    if (tF >= (float)0.01 && tF <= 10000.0f) return tF;
+    return FMAX;
+}
+// normal = -sign(rd) * step(t1.yzx, t1) * step(t1.zxy, t1)   (Object.hpp:189,193)
+__device__ __forceinline__ V3 ibox_normal(const BoxRay& br, V3 t1) {
+    V3 s1 = v3(t1.y <= t1.x ? 1.0f : 0.0f, t1.z <= t1.y ? 1.0f : 0.0f, t1.x <= t1.z ? 1.0f : 0.0f);
+    V3 s2 = v3(t1.z <= t1.x ? 1.0f : 0.0f, t1.x <= t1.y ? 1.0f : 0.0f, t1.y <= t1.z ? 1.0f : 0.0f);
+    return v3((br.sgn.x * -1) * s1.x * s2.x, (br.sgn.y * -1) * s1.y * s2.y, (br.sgn.z * -1) * s1.z * s2.z);
+}
+
+struct Hit {
+    float t;   // distance of the recorded hit
+    int prim;  // primitive id, -1 = miss (rayHit.valid == false)
+    V3 n, p;   // normal, point (valid when prim >= 0)
+};
+
+// GetClosestObject (Raytracer.cpp:123-140) over the LDS scene.
+// Strict `<` keeps the lower list index on ties (:132); boxes are scanned after the
+// spheres, so a box additionally wins an exact tie when its list index is lower.
+__device__ __forceinline__ Hit closest_hit(const Lds& S, V3 o, V3 d) {
+    float best = __builtin_inff();
+    int bp = -1;
+    const int ns = S.ns, nb = S.nb;
+    for (int j = 0; j < ns; ++j) {
+        const float4 s = S.sphere(j);
+        // Sphere::line_sphere_intersection (Object.hpp:104-141)
+        float Lx = s.x - o.x, Ly = s.y - o.y, Lz = s.z - o.z;  // :115
+        float tc = fabsf((Lx * d.x + Ly * d.y) + Lz * d.z);    // :118-119
+        float qx = d.x * tc + o.x, qy = d.y * tc + o.y, qz = d.z * tc + o.z;  // :121
+        float ex = qx - s.x, ey = qy - s.y, ez = qz - s.z;     // :124
+        float d2 = (ex * ex + ey * ey) + ez * ez;              // :125
+        bool cand = !(d2 > s.w);                                // :127
+        if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {        // wave-uniform skip
+            float t1 = tc - sqrtf(s.w - d2);                    // :131-133
+            if (cand && t1 < best) {                            // Raytracer.cpp:130-132
+                best = t1;
+                bp = j;
+            }
+        }
+    }
+    Hit h;
+    V3 bt1 = v3(0, 0, 0);
+    BoxRay br;
+    if (nb > 0) {
+        br = box_ray_setup(d);
+        int border = 0x7fffffff;
+        if (bp >= 0) border = __float_as_int(S.mat(bp, 2).w);
+        for (int j = 0; j < nb; ++j) {
+            const float4 c = S.box_c(j), hs = S.box_h(j);
+            V3 t1;
+            float dist = ibox_dist(br, v3(o.x - c.x, o.y - c.y, o.z - c.z), v3(hs.x, hs.y, hs.z), t1);
+            bool valid = dist != 3.402823466e+38f;  // Object.hpp:231
+            if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
+                int ord = __float_as_int(S.mat(ns + j, 2).w);
+                if (valid && (dist < best || (dist == best && ord < border))) {
+                    best = dist;
+                    bp = ns + j;
+                    border = ord;
+                    bt1 = t1;
+                }
+            }
+        }
+    }
+    h.t = best;
+    h.prim = bp;
+    h.p = v3(o.x + d.x * best, o.y + d.y * best, o.z + d.z * best);  // Object.hpp:136 / :229
+    if (bp >= ns) {
+        h.n = ibox_normal(br, bt1);
+    } else if (bp >= 0) {
+        const float4 s = S.sphere(bp);
+        h.n = normalized(v3(h.p.x - s.x, h.p.y - s.y, h.p.z - s.z));  // Object.hpp:137
+    } else {
+        h.n = v3(0, 0, 0);
+    }
+    return h;
+}
+
+struct RGB {
+    float r, g, b;
+};
+// Color::Lerp (Common.hpp:275-279), rgb part
+__device__ __forceinline__ RGB color_lerp(RGB a, RGB b, float t) {
+    return RGB{clamp0(a.r * (1 - t) + b.r * t), clamp0(a.g * (1 - t) + b.g * t), clamp0(a.b * (1 - t) + b.b * t)};
+}
+
+// GetEnvironmentColor (Raytracer.cpp:77-89)
+__device__ __forceinline__ RGB environment(const KernelParams& P, V3 d) {
+    RGB Sky{clamp0(P.sky[0]), clamp0(P.sky[1]), clamp0(P.sky[2])};
+    RGB Horizon{clamp0(P.horizon[0]), clamp0(P.horizon[1]), clamp0(P.horizon[2])};
+    RGB Ground{clamp0(P.ground[0]), clamp0(P.ground[1]), clamp0(P.ground[2])};
+    float upd = (d.x * 0.0f + d.y * 1.0f) + d.z * 0.0f;  // Dot(rayDirection, WORLDUP) :78
+    float sd = (d.x * (P.sun_dir[0] * -1) + d.y * (P.sun_dir[1] * -1)) + d.z * (P.sun_dir[2] * -1);
+    bool sunny = (double)sd > 0.99;  // :79 float vs double literal
+    RGB Sun{sunny ? clamp0(P.sun[0]) : 0.0f, sunny ? clamp0(P.sun[1]) : 0.0f, sunny ? clamp0(P.sun[2]) : 0.0f};
+    RGB t;
+    if (upd > 0) {
+        t = color_lerp(Horizon, Sky, srt_powf(upd, 0.1f));  // :81
+        RGB sky01{clamp0(Sky.r * 0.1f), clamp0(Sky.g * 0.1f), clamp0(Sky.b * 0.1f)};
+        t = color_lerp(t, sky01, upd);                      // :82
+    } else {
+        upd = fabsf(upd);                                   // :86
+        t = color_lerp(Horizon, Ground, srt_powf(upd, .05f));  // :87
+    }
+    return RGB{clamp0(t.r + Sun.r), clamp0(t.g + Sun.g), clamp0(t.b + Sun.b)};  // :83 / :87
+}
+
+// (int)f with x86 cvttss2si semantics (reference platform), see oracle cvtt_x86
+__device__ __forceinline__ int cvtt_x86(float f) {
+    if (f != f || f >= 2147483648.0f || f < -2147483648.0f) return (int)0x80000000;
+    return (int)f;
+}
+__device__ __forceinline__ uint32_t pack_channel(float v) {  // Common.hpp:190-203
+    int s = cvtt_x86(v * 255);
+    if (s > 255) s = 255;
+    return (uint32_t)(uint8_t)s;
+}
+
+__global__ void __launch_bounds__(WG_THREADS) pathtrace_kernel(const KernelParams P) {
+    extern __shared__ float4 lds_scene[];
+    // ---- stage the scene image into LDS (coalesced 16-byte loads) -----------------
+    for (int i = threadIdx.x; i < P.scene_vec4; i += WG_THREADS) lds_scene[i] = P.scene[i];
+    __syncthreads();
+    Lds S{lds_scene, P.ns, P.nb};
+
+    // ---- pixel of this lane ----------------------------------------------------------
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tx = blockIdx.x * WG_W + (wave % WG_TILES_X) * TILE_W + (lane & (TILE_W - 1));
+    const int ty = blockIdx.y * WG_H + (wave / WG_TILES_X) * TILE_H + (lane / TILE_W);
+    const int W = P.width, H = P.height;
+    const bool in_range = tx < W && ty < P.rows;
+    const int x = in_range ? tx : 0, y = in_range ? (P.y0 + ty) : P.y0;
+    const uint32_t pixel = (uint32_t)(x + y * W);
+
+    // ---- GetRayDirection (Raytracer.cpp:106-122) ----------------------------------
+    float nX = ((float)x / (float)W) * 2 - 1;
+    float nY = ((float)y / (float)H) * 2 - 1;
+    V3 u = v3(P.right_rd[0] * nX, P.right_rd[1] * nX, P.right_rd[2] * nX);
+    V3 vv = v3(P.up_ld[0] * nY, P.up_ld[1] * nY, P.up_ld[2] * nY);
+    const V3 dir0 = normalized(v3((u.x + vv.x) + P.fwd_clip[0], (u.y + vv.y) + P.fwd_clip[1], (u.z + vv.z) + P.fwd_clip[2]));
+    const V3 cam = v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
+
+    // ---- primary hit: identical for every sample ------------------------------------
+    const Hit h0 = closest_hit(S, cam, dir0);
+
+    float4 acc = make_float4(0, 0, 0, 0);
+    const size_t acc_idx = (size_t)pixel;
+    const bool reset = (P.flags & 1u) != 0;
+    if (in_range && !reset) acc = P.accumulator[acc_idx];
+
+    const uint32_t count = P.sample_count;
+    const int B = P.max_bounces;
+    uint32_t s = 0;  // samples finished by this lane
+    unsigned rays = 0;
+
+    // SetScreenPixel accumulate half (Raytracer.cpp:65-71); colour alpha is always +0
+    auto accumulate = [&](RGB c) {
+        const uint32_t frame = P.first_sample + s;
+        if (s == 0 && reset) {
+            acc = make_float4(c.r, c.g, c.b, 0.0f);
+        } else {
+            float weight = (float)(1.0 / (double)(int)frame);  // :66
+            float om = 1 - weight;
+            acc.x = clamp0(clamp0(acc.x * om) + clamp0(c.r * weight));  // :67
+            acc.y = clamp0(clamp0(acc.y * om) + clamp0(c.g * weight));
+            acc.z = clamp0(clamp0(acc.z * om) + clamp0(c.b * weight));
+            acc.w = clamp0(clamp0(acc.w * om) + clamp0(0.0f * weight));
+        }
+        ++s;
+    };
+
+    bool done = !in_range;
+    // path state
+    RGB L{0, 0, 0}, T{0, 0, 0};
+    V3 sray = dir0, hn = h0.n, hp = h0.p;
+    int hprim = h0.prim;
+    float spec = 0.0f;
+    int bounce = 0;
+    uint32_t rng = 0;
+
+    RGB E0{0, 0, 0}, Base0{0, 0, 0};
+    float specAmt0 = 0;
+    if (h0.prim >= 0) {
+        float4 m0 = S.mat(h0.prim, 0), m1 = S.mat(h0.prim, 1);
+        specAmt0 = m0.y;
+        Base0 = RGB{clamp0(m0.z), clamp0(m0.w), clamp0(m1.x)};
+        E0 = RGB{clamp0(m1.y), clamp0(m1.z), clamp0(m1.w)};
+    }
+
+    auto start_path = [&]() {  // Raytracer.cpp:162-166 for the next sample of this lane
+        rng = srt_rng_key(P.seed, pixel, P.first_sample + s);
+        uint32_t r = srt_mix32(rng) >> 17;
+        rng += 0x9E3779B9U;
+        spec = (specAmt0 >= ((float)r / (float)SRT_RAND_MAX)) ? 1.0f : 0.0f;  // :165
+        L = E0;                                                                 // :162
+        T = Base0;                                                              // :163
+        sray = dir0;                                                            // :164
+        hn = h0.n;
+        hp = h0.p;
+        hprim = h0.prim;
+        bounce = 0;
+    };
+
+    if (!done) {
+        if (h0.prim < 0) {  // primary miss: the sample colour is env(dir0) every frame (:143-145)
+            RGB c = environment(P, dir0);
+            for (uint32_t i = 0; i < count; ++i) accumulate(c);
+            rays += count;
+            done = true;
+        } else if (B <= 0) {  // no bounce loop: colour = EmissiveColor (:162,212)
+            for (uint32_t i = 0; i < count; ++i) accumulate(E0);
+            rays += count;
+            done = true;
+        } else {
+            start_path();
+        }
+    }
+
+    // ---- bounce loop with per-lane path regeneration ----------------------------------
+    while (__builtin_amdgcn_ballot_w64(!done) != 0ull) {
+        if (!done) {
+            if (bounce != 0) {  // :169-171
+                T = RGB{clamp0(T.r * 0.8f), clamp0(T.g * 0.8f), clamp0(T.b * 0.8f)};
+            }
+            // reflectedRay = sray.Reflect(normal)  (:172, Common.hpp:163-165)
+            float k2 = 2 * dot3(sray, hn);
+            V3 refl = v3(sray.x - hn.x * k2, sray.y - hn.y * k2, sray.z - hn.z * k2);
+            // GetRandomNormalOrientedHemisphere (:90-105): exactly three draws, x then y then z
+            uint32_t r0 = srt_mix32(rng) >> 17;
+            uint32_t r1 = srt_mix32(rng + 0x9E3779B9U) >> 17;
+            uint32_t r2 = srt_mix32(rng + 2u * 0x9E3779B9U) >> 17;
+            rng += 3u * 0x9E3779B9U;
+            V3 sr = v3(((float)r0 / (float)SRT_RAND_MAX - 0.5f) * 2, ((float)r1 / (float)SRT_RAND_MAX - 0.5f) * 2,
+                       ((float)r2 / (float)SRT_RAND_MAX - 0.5f) * 2);
+            sr = normalized(sr);
+            if (dot3(sr, hn) < 0) sr = v3(sr.x * -1, sr.y * -1, sr.z * -1);
+            // float3::Lerp(sray, reflectedRay, Smoothness * specularProb)  (:175)
+            float tt = S.mat(hprim, 0).x * spec;
+            V3 l = v3(sr.x * (1 - tt) + refl.x * tt, sr.y * (1 - tt) + refl.y * tt, sr.z * (1 - tt) + refl.z * tt);
+            sray = normalized(l);  // :176
+            const float ofs = .00001f;
+            V3 o = v3(hp.x + hn.x * ofs, hp.y + hn.y * ofs, hp.z + hn.z * ofs);  // :177
+            Hit h = closest_hit(S, o, sray);
+            ++rays;
+            bool end_path;
+            if (h.prim < 0) {  // :178-181
+                RGB e = environment(P, sray);
+                L = RGB{clamp0(L.r + clamp0(e.r * T.r)), clamp0(L.g + clamp0(e.g * T.g)), clamp0(L.b + clamp0(e.b * T.b))};
+                end_path = true;
+            } else {
+                float4 m0 = S.mat(h.prim, 0), m1 = S.mat(h.prim, 1), m2 = S.mat(h.prim, 2);
+                uint32_t r = srt_mix32(rng) >> 17;
+                rng += 0x9E3779B9U;
+                spec = (m0.y >= ((float)r / (float)SRT_RAND_MAX)) ? 1.0f : 0.0f;  // :182
+                RGB Em{clamp0(m1.y), clamp0(m1.z), clamp0(m1.w)};
+                L = RGB{clamp0(L.r + clamp0(Em.r * T.r)), clamp0(L.g + clamp0(Em.g * T.g)), clamp0(L.b + clamp0(Em.b * T.b))};  // :183
+                RGB Bc{clamp0(m0.z), clamp0(m0.w), clamp0(m1.x)}, Sc{clamp0(m2.x), clamp0(m2.y), clamp0(m2.z)};
+                RGB f = color_lerp(Bc, Sc, spec);                                   // :184
+                T = RGB{clamp0(T.r * f.r), clamp0(T.g * f.g), clamp0(T.b * f.b)};
+                hn = h.n;
+                hp = h.p;
+                hprim = h.prim;
+                ++bounce;
+                end_path = bounce >= B;
+            }
+            if (end_path) {
+                ++rays;  // the sample's primary GetClosestObject call (:142)
+                accumulate(L);
+                if (s >= count)
+                    done = true;
+                else
+                    start_path();
+            }
+        }
+    }
+
+    // ---- SetScreenPixel tone-map + pack (Raytracer.cpp:73-75) -------------------------
+    if (in_range) {
+        P.accumulator[acc_idx] = acc;
+        float r = clamp0(acc.x / clamp0(1.0f + acc.x));
+        float g = clamp0(acc.y / clamp0(1.0f + acc.y));
+        float b = clamp0(acc.z / clamp0(1.0f + acc.z));
+        float a = clamp0(acc.w / clamp0(0.0f + acc.w));
+        uint32_t px = pack_channel(a) << 24 | pack_channel(r) << 16 | pack_channel(g) << 8 | pack_channel(b);
+        P.framebuffer[(size_t)(H - 1 - y) * W + x] = px;  // :64
+    }
+    if (P.flags & 2u) {  // SRT_RENDER_COUNT_RAYS
+        unsigned long long tot = rays;
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
+        if (lane == 0 && tot) atomicAdd(P.ray_counter, tot);
+    }
+}
+
+}  // namespace srt

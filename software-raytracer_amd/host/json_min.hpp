@@ -1,0 +1,487 @@
+// json_min.hpp — a small JSON DOM for the scene files.
+//
+// The reference reads and writes scenes through nlohmann/json 3.11.2 (vendored there,
+// Raytracer/json.hpp); that library is not part of this repo.  This is an independent,
+// minimal implementation of the two behaviours the scene format depends on:
+//   * parse(): RFC 8259 JSON -> DOM; numbers keep "integer vs float" like nlohmann does
+//     (an integer literal converts to float exactly the way `float f = json` does).
+//   * dump(indent): object keys in sorted (std::map) order, `indent` spaces per level,
+//     floats printed as the shortest decimal that round-trips the double, in nlohmann's
+//     layout ("1.0", "0.20000000298023224", "1e-05"), empty array "[]", empty object "{}".
+#pragma once
+
+#include <charconv>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace srt_host {
+
+class JsonError : public std::runtime_error {
+   public:
+    explicit JsonError(const std::string& m) : std::runtime_error(m) {}
+};
+
+class Json {
+   public:
+    enum class Kind { Null, Bool, Int, Uint, Float, String, Array, Object };
+    using Array = std::vector<Json>;
+    using Object = std::map<std::string, Json>;
+
+    Json() = default;
+    Json(std::nullptr_t) {}
+    Json(bool b) : kind_(Kind::Bool), b_(b) {}
+    Json(int v) : kind_(Kind::Int), i_(v) {}
+    Json(int64_t v) : kind_(Kind::Int), i_(v) {}
+    Json(uint64_t v) : kind_(Kind::Uint), u_(v) {}
+    Json(double v) : kind_(Kind::Float), d_(v) {}
+    Json(float v) : kind_(Kind::Float), d_((double)v) {}  // float -> double, as nlohmann stores it
+    Json(const char* s) : kind_(Kind::String), s_(s) {}
+    Json(const std::string& s) : kind_(Kind::String), s_(s) {}
+    static Json array() {
+        Json j;
+        j.kind_ = Kind::Array;
+        return j;
+    }
+    static Json array(std::initializer_list<Json> v) {
+        Json j = array();
+        j.a_ = v;
+        return j;
+    }
+    static Json object() {
+        Json j;
+        j.kind_ = Kind::Object;
+        return j;
+    }
+
+    Kind kind() const { return kind_; }
+    bool is_null() const { return kind_ == Kind::Null; }
+    bool is_number() const { return kind_ == Kind::Int || kind_ == Kind::Uint || kind_ == Kind::Float; }
+    bool is_string() const { return kind_ == Kind::String; }
+    bool is_array() const { return kind_ == Kind::Array; }
+    bool is_object() const { return kind_ == Kind::Object; }
+
+    // ---- typed access; wrong type throws like nlohmann's type_error ------------------
+    float as_float() const {
+        switch (kind_) {
+            case Kind::Float: return (float)d_;
+            case Kind::Int: return (float)i_;
+            case Kind::Uint: return (float)u_;
+            case Kind::Bool: return b_ ? 1.0f : 0.0f;  // nlohmann converts booleans to arithmetic types
+            default: throw JsonError(std::string("type must be number, but is ") + type_name());
+        }
+    }
+    double as_double() const {
+        switch (kind_) {
+            case Kind::Float: return d_;
+            case Kind::Int: return (double)i_;
+            case Kind::Uint: return (double)u_;
+            case Kind::Bool: return b_ ? 1.0 : 0.0;
+            default: throw JsonError(std::string("type must be number, but is ") + type_name());
+        }
+    }
+    const std::string& as_string() const {
+        if (kind_ != Kind::String) throw JsonError(std::string("type must be string, but is ") + type_name());
+        return s_;
+    }
+    const Array& items() const {
+        if (kind_ != Kind::Array) throw JsonError(std::string("type must be array, but is ") + type_name());
+        return a_;
+    }
+    const Object& members() const {
+        if (kind_ != Kind::Object) throw JsonError(std::string("type must be object, but is ") + type_name());
+        return o_;
+    }
+
+    bool contains(const std::string& key) const { return kind_ == Kind::Object && o_.count(key) != 0; }
+
+    // value["key"] on a non-const nlohmann json inserts null for a missing key and turns a
+    // null value into an object; on any other non-object it throws.
+    Json& operator[](const std::string& key) {
+        if (kind_ == Kind::Null) kind_ = Kind::Object;
+        if (kind_ != Kind::Object)
+            throw JsonError(std::string("cannot use operator[] with a string argument with ") + type_name());
+        return o_[key];
+    }
+    // value[i] on an array; nlohmann fills with nulls when i >= size (null becomes array).
+    Json& operator[](size_t i) {
+        if (kind_ == Kind::Null) kind_ = Kind::Array;
+        if (kind_ != Kind::Array)
+            throw JsonError(std::string("cannot use operator[] with a numeric argument with ") + type_name());
+        if (i >= a_.size()) a_.resize(i + 1);
+        return a_[i];
+    }
+    void push_back(const Json& v) {
+        if (kind_ == Kind::Null) kind_ = Kind::Array;
+        if (kind_ != Kind::Array) throw JsonError("cannot use push_back() with " + std::string(type_name()));
+        a_.push_back(v);
+    }
+    size_t size() const { return kind_ == Kind::Array ? a_.size() : kind_ == Kind::Object ? o_.size() : kind_ == Kind::Null ? 0 : 1; }
+
+    const char* type_name() const {
+        switch (kind_) {
+            case Kind::Null: return "null";
+            case Kind::Bool: return "boolean";
+            case Kind::String: return "string";
+            case Kind::Array: return "array";
+            case Kind::Object: return "object";
+            default: return "number";
+        }
+    }
+
+    // ---- parse ---------------------------------------------------------------------------
+    static Json parse(const std::string& text) {
+        Parser p{text.data(), text.data() + text.size()};
+        // nlohmann skips a UTF-8 byte order mark
+        if (text.size() >= 3 && (unsigned char)text[0] == 0xEF && (unsigned char)text[1] == 0xBB && (unsigned char)text[2] == 0xBF)
+            p.cur += 3;
+        Json v = p.value(0);
+        p.ws();
+        if (p.cur != p.end) p.fail("unexpected trailing characters");
+        return v;
+    }
+
+    // ---- dump ----------------------------------------------------------------------------
+    std::string dump(int indent = -1) const {
+        std::string out;
+        dump_to(out, indent, 0);
+        return out;
+    }
+
+    // shortest round-trip decimal of a double in nlohmann's layout
+    static std::string format_double(double v) {
+        if (!std::isfinite(v)) return "null";  // nlohmann dumps NaN/inf as null
+        if (v == 0) return std::signbit(v) ? "-0.0" : "0.0";
+        char digits[32];
+        auto r = std::to_chars(digits, digits + sizeof digits, std::fabs(v), std::chars_format::scientific);
+        // digits = d[.ddd]e[+-]XX  -> mantissa digits + decimal exponent
+        std::string sci(digits, r.ptr);
+        size_t epos = sci.find('e');
+        std::string mant = sci.substr(0, epos);
+        int exp10 = std::atoi(sci.c_str() + epos + 1);
+        std::string ds;
+        for (char c : mant)
+            if (c != '.') ds.push_back(c);
+        const int k = (int)ds.size();  // number of significant digits
+        const int n = exp10 + 1;       // position of the decimal point relative to the digits
+        std::string out = v < 0 ? "-" : "";
+        const int min_exp = -4, max_exp = 15;
+        if (k <= n && n <= max_exp) {  // digits[000].0
+            out += ds;
+            out.append((size_t)(n - k), '0');
+            out += ".0";
+        } else if (0 < n && n <= max_exp) {  // dig.its
+            out += ds.substr(0, (size_t)n);
+            out += ".";
+            out += ds.substr((size_t)n);
+        } else if (min_exp < n && n <= 0) {  // 0.[000]digits
+            out += "0.";
+            out.append((size_t)(-n), '0');
+            out += ds;
+        } else {  // d[.igits]e+-XX
+            out += ds.substr(0, 1);
+            if (k > 1) {
+                out += ".";
+                out += ds.substr(1);
+            }
+            out += "e";
+            int e = n - 1;
+            out += e < 0 ? "-" : "+";
+            e = e < 0 ? -e : e;
+            char buf[8];
+            std::snprintf(buf, sizeof buf, e < 10 ? "0%d" : "%d", e);
+            out += buf;
+        }
+        return out;
+    }
+
+   private:
+    Kind kind_ = Kind::Null;
+    bool b_ = false;
+    int64_t i_ = 0;
+    uint64_t u_ = 0;
+    double d_ = 0;
+    std::string s_;
+    Array a_;
+    Object o_;
+
+    static void dump_string(std::string& out, const std::string& s) {
+        out.push_back('"');
+        for (unsigned char c : s) {
+            switch (c) {
+                case '"': out += "\\\""; break;
+                case '\\': out += "\\\\"; break;
+                case '\b': out += "\\b"; break;
+                case '\f': out += "\\f"; break;
+                case '\n': out += "\\n"; break;
+                case '\r': out += "\\r"; break;
+                case '\t': out += "\\t"; break;
+                default:
+                    if (c < 0x20) {
+                        char buf[8];
+                        std::snprintf(buf, sizeof buf, "\\u%04x", c);
+                        out += buf;
+                    } else {
+                        out.push_back((char)c);
+                    }
+            }
+        }
+        out.push_back('"');
+    }
+
+    void dump_to(std::string& out, int indent, int level) const {
+        const bool pretty = indent >= 0;
+        auto nl = [&](int lvl) {
+            if (pretty) {
+                out.push_back('\n');
+                out.append((size_t)(lvl * indent), ' ');
+            }
+        };
+        switch (kind_) {
+            case Kind::Null: out += "null"; break;
+            case Kind::Bool: out += b_ ? "true" : "false"; break;
+            case Kind::Int: out += std::to_string(i_); break;
+            case Kind::Uint: out += std::to_string(u_); break;
+            case Kind::Float: out += format_double(d_); break;
+            case Kind::String: dump_string(out, s_); break;
+            case Kind::Array:
+                if (a_.empty()) {
+                    out += "[]";
+                    break;
+                }
+                out.push_back('[');
+                for (size_t i = 0; i < a_.size(); ++i) {
+                    nl(level + 1);
+                    a_[i].dump_to(out, indent, level + 1);
+                    if (i + 1 < a_.size()) out.push_back(',');
+                }
+                nl(level);
+                out.push_back(']');
+                break;
+            case Kind::Object: {
+                if (o_.empty()) {
+                    out += "{}";
+                    break;
+                }
+                out.push_back('{');
+                size_t i = 0;
+                for (const auto& kv : o_) {
+                    nl(level + 1);
+                    dump_string(out, kv.first);
+                    out += pretty ? ": " : ":";
+                    kv.second.dump_to(out, indent, level + 1);
+                    if (++i < o_.size()) out.push_back(',');
+                }
+                nl(level);
+                out.push_back('}');
+                break;
+            }
+        }
+    }
+
+    struct Parser {
+        const char* cur;
+        const char* end;
+        [[noreturn]] void fail(const char* what) const { throw JsonError(std::string("parse error: ") + what); }
+        void ws() {
+            while (cur != end && (*cur == ' ' || *cur == '\t' || *cur == '\n' || *cur == '\r')) ++cur;
+        }
+        bool lit(const char* s) {
+            size_t n = std::strlen(s);
+            if ((size_t)(end - cur) >= n && std::memcmp(cur, s, n) == 0) {
+                cur += n;
+                return true;
+            }
+            return false;
+        }
+        static void utf8(std::string& out, unsigned cp) {
+            if (cp < 0x80)
+                out.push_back((char)cp);
+            else if (cp < 0x800) {
+                out.push_back((char)(0xC0 | (cp >> 6)));
+                out.push_back((char)(0x80 | (cp & 0x3F)));
+            } else if (cp < 0x10000) {
+                out.push_back((char)(0xE0 | (cp >> 12)));
+                out.push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
+                out.push_back((char)(0x80 | (cp & 0x3F)));
+            } else {
+                out.push_back((char)(0xF0 | (cp >> 18)));
+                out.push_back((char)(0x80 | ((cp >> 12) & 0x3F)));
+                out.push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
+                out.push_back((char)(0x80 | (cp & 0x3F)));
+            }
+        }
+        unsigned hex4() {
+            if (end - cur < 4) fail("truncated \\u escape");
+            unsigned v = 0;
+            for (int i = 0; i < 4; ++i) {
+                char c = *cur++;
+                v <<= 4;
+                if (c >= '0' && c <= '9')
+                    v |= (unsigned)(c - '0');
+                else if (c >= 'a' && c <= 'f')
+                    v |= (unsigned)(c - 'a' + 10);
+                else if (c >= 'A' && c <= 'F')
+                    v |= (unsigned)(c - 'A' + 10);
+                else
+                    fail("bad \\u escape");
+            }
+            return v;
+        }
+        std::string string() {
+            if (cur == end || *cur != '"') fail("expected string");
+            ++cur;
+            std::string out;
+            for (;;) {
+                if (cur == end) fail("unterminated string");
+                unsigned char c = (unsigned char)*cur++;
+                if (c == '"') break;
+                if (c < 0x20) fail("control character in string");
+                if (c != '\\') {
+                    out.push_back((char)c);
+                    continue;
+                }
+                if (cur == end) fail("unterminated escape");
+                char e = *cur++;
+                switch (e) {
+                    case '"': out.push_back('"'); break;
+                    case '\\': out.push_back('\\'); break;
+                    case '/': out.push_back('/'); break;
+                    case 'b': out.push_back('\b'); break;
+                    case 'f': out.push_back('\f'); break;
+                    case 'n': out.push_back('\n'); break;
+                    case 'r': out.push_back('\r'); break;
+                    case 't': out.push_back('\t'); break;
+                    case 'u': {
+                        unsigned cp = hex4();
+                        if (cp >= 0xD800 && cp <= 0xDBFF) {
+                            if (end - cur < 2 || cur[0] != '\\' || cur[1] != 'u') fail("unpaired surrogate");
+                            cur += 2;
+                            unsigned lo = hex4();
+                            if (lo < 0xDC00 || lo > 0xDFFF) fail("bad low surrogate");
+                            cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+                        } else if (cp >= 0xDC00 && cp <= 0xDFFF) {
+                            fail("unpaired surrogate");
+                        }
+                        utf8(out, cp);
+                        break;
+                    }
+                    default: fail("bad escape");
+                }
+            }
+            return out;
+        }
+        Json number() {
+            const char* s = cur;
+            bool is_float = false;
+            if (cur != end && *cur == '-') ++cur;
+            if (cur == end) fail("bad number");
+            if (*cur == '0') {
+                ++cur;
+            } else if (*cur >= '1' && *cur <= '9') {
+                while (cur != end && *cur >= '0' && *cur <= '9') ++cur;
+            } else {
+                fail("bad number");
+            }
+            if (cur != end && *cur == '.') {
+                is_float = true;
+                ++cur;
+                if (cur == end || *cur < '0' || *cur > '9') fail("bad fraction");
+                while (cur != end && *cur >= '0' && *cur <= '9') ++cur;
+            }
+            if (cur != end && (*cur == 'e' || *cur == 'E')) {
+                is_float = true;
+                ++cur;
+                if (cur != end && (*cur == '+' || *cur == '-')) ++cur;
+                if (cur == end || *cur < '0' || *cur > '9') fail("bad exponent");
+                while (cur != end && *cur >= '0' && *cur <= '9') ++cur;
+            }
+            if (!is_float) {
+                if (*s == '-') {
+                    int64_t v = 0;
+                    auto r = std::from_chars(s, cur, v);
+                    if (r.ec == std::errc() && r.ptr == cur) return Json(v);
+                } else {
+                    uint64_t v = 0;
+                    auto r = std::from_chars(s, cur, v);
+                    if (r.ec == std::errc() && r.ptr == cur) return v <= (uint64_t)INT64_MAX ? Json((int64_t)v) : Json(v);
+                }
+                // out of integer range: falls through to double, like nlohmann
+            }
+            double d = 0;
+            auto r = std::from_chars(s, cur, d);
+            if (r.ec == std::errc::result_out_of_range) fail("number overflow");
+            if (r.ec != std::errc() || r.ptr != cur) fail("bad number");
+            return Json(d);
+        }
+        Json value(int depth) {
+            if (depth > 512) fail("nesting too deep");
+            ws();
+            if (cur == end) fail("unexpected end of input");
+            char c = *cur;
+            if (c == '{') {
+                ++cur;
+                Json o = Json::object();
+                ws();
+                if (cur != end && *cur == '}') {
+                    ++cur;
+                    return o;
+                }
+                for (;;) {
+                    ws();
+                    std::string k = string();
+                    ws();
+                    if (cur == end || *cur != ':') fail("expected ':'");
+                    ++cur;
+                    o.o_[k] = value(depth + 1);  // duplicate keys: last one wins (nlohmann default)
+                    ws();
+                    if (cur != end && *cur == ',') {
+                        ++cur;
+                        continue;
+                    }
+                    if (cur != end && *cur == '}') {
+                        ++cur;
+                        return o;
+                    }
+                    fail("expected ',' or '}'");
+                }
+            }
+            if (c == '[') {
+                ++cur;
+                Json a = Json::array();
+                ws();
+                if (cur != end && *cur == ']') {
+                    ++cur;
+                    return a;
+                }
+                for (;;) {
+                    a.a_.push_back(value(depth + 1));
+                    ws();
+                    if (cur != end && *cur == ',') {
+                        ++cur;
+                        continue;
+                    }
+                    if (cur != end && *cur == ']') {
+                        ++cur;
+                        return a;
+                    }
+                    fail("expected ',' or ']'");
+                }
+            }
+            if (c == '"') return Json(string());
+            if (lit("true")) return Json(true);
+            if (lit("false")) return Json(false);
+            if (lit("null")) return Json(nullptr);
+            if (c == '-' || (c >= '0' && c <= '9')) return number();
+            fail("unexpected character");
+        }
+    };
+};
+
+}  // namespace srt_host
