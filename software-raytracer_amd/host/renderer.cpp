@@ -1,0 +1,128 @@
+// renderer.cpp — see renderer.hpp.
+#include "renderer.hpp"
+
+namespace srt_host {
+
+void PathTraceRenderer::check(int rc, const char* what) {
+    if (rc != SRT_OK) {
+        const char* msg = srt_last_error(ctx_);
+        throw RendererError(rc, std::string(what) + ": " + (msg ? msg : "?"));
+    }
+}
+
+PathTraceRenderer::PathTraceRenderer(int device, int width, int height)
+    : width_(width), height_(height), row_begin_(0), row_end_(height) {
+    int rc = srt_create(device, width, height, &ctx_);
+    if (rc != SRT_OK) {
+        const char* msg = srt_last_error(nullptr);
+        throw RendererError(rc, std::string("srt_create: ") + (msg ? msg : "?"));
+    }
+}
+
+PathTraceRenderer::~PathTraceRenderer() { srt_destroy(ctx_); }
+
+void PathTraceRenderer::SetScene(const Scene& scene) {
+    std::vector<srt_object> flat = scene.Flatten();
+    check(srt_set_scene(ctx_, flat.data(), flat.size()), "srt_set_scene");
+    doSetFrame_ = true;
+}
+
+void PathTraceRenderer::SetEnvironment(const srt_environment& env) {
+    check(srt_set_environment(ctx_, &env), "srt_set_environment");
+    doSetFrame_ = true;
+}
+
+void PathTraceRenderer::SetRowBand(int begin, int end) {
+    if (begin < 0 || end > height_ || begin >= end) throw RendererError(SRT_ERR_INVALID_ARG, "SetRowBand: bad band");
+    row_begin_ = begin;
+    row_end_ = end;
+    doSetFrame_ = true;
+}
+
+void PathTraceRenderer::push_camera() {
+    srt_camera c{};
+    const Vec3* src[4] = {&camera.position, &camera.right, &camera.up, &camera.forward};
+    float* dst[4] = {c.position, c.right, c.up, c.forward};
+    for (int i = 0; i < 4; ++i) {
+        dst[i][0] = src[i]->x;
+        dst[i][1] = src[i]->y;
+        dst[i][2] = src[i]->z;
+    }
+    c.fov_degrees = FOV;
+    check(srt_set_camera(ctx_, &c), "srt_set_camera");
+}
+
+bool PathTraceRenderer::RenderFrame() {
+    bool setFrame;
+    if (doSetFrame_) {
+        // loop iteration 1 after an edit (Raytracer.cpp:577-582): setFrame, ACC = 1,
+        // progressiveResolutionScaler = 1/4 -> a quarter-resolution frame (not rendered here)
+        ACCUMULATIONFRAMES = 1;
+        doSetFrame_ = false;
+        if (ACCUMULATIONFRAMES == TARGETFRAMES) return false;  // :572-574
+        // iteration 2 (:584-590): scaler != 1 -> setFrame = true; ACC += 1
+        setFrame = true;
+        ACCUMULATIONFRAMES += 1;
+    } else {
+        if (ACCUMULATIONFRAMES == TARGETFRAMES) return false;  // :572-574
+        setFrame = false;                                      // :585
+        ACCUMULATIONFRAMES += 1;                               // :590
+    }
+    push_camera();
+    srt_render_params p{};
+    p.row_begin = row_begin_;
+    p.row_end = row_end_;
+    p.first_sample = (uint32_t)ACCUMULATIONFRAMES;
+    p.sample_count = 1;
+    p.max_bounces = MAXBOUNCES < 0 ? 0 : MAXBOUNCES;  // :475
+    p.seed = seed;
+    p.flags = setFrame ? SRT_RENDER_RESET : 0;
+    check(srt_render(ctx_, &p), "srt_render");
+    next_clean_sample_ = (uint32_t)ACCUMULATIONFRAMES + 1;
+    return true;
+}
+
+void PathTraceRenderer::RenderSamples(uint32_t count, bool count_rays) {
+    if (count == 0) return;
+    bool reset = doSetFrame_;
+    if (reset) next_clean_sample_ = 1;
+    doSetFrame_ = false;
+    push_camera();
+    srt_render_params p{};
+    p.row_begin = row_begin_;
+    p.row_end = row_end_;
+    p.first_sample = next_clean_sample_;
+    p.sample_count = count;
+    p.max_bounces = MAXBOUNCES < 0 ? 0 : MAXBOUNCES;
+    p.seed = seed;
+    p.flags = (reset ? SRT_RENDER_RESET : 0) | (count_rays ? SRT_RENDER_COUNT_RAYS : 0);
+    check(srt_render(ctx_, &p), "srt_render");
+    next_clean_sample_ += count;
+    ACCUMULATIONFRAMES = (int)(next_clean_sample_ - 1);
+}
+
+void PathTraceRenderer::Wait() { check(srt_wait(ctx_), "srt_wait"); }
+
+bool PathTraceRenderer::Done() {
+    int d = 0;
+    check(srt_poll(ctx_, &d), "srt_poll");
+    return d != 0;
+}
+
+srt_stats PathTraceRenderer::Stats() {
+    srt_stats s{};
+    check(srt_get_stats(ctx_, &s), "srt_get_stats");
+    return s;
+}
+
+void PathTraceRenderer::ReadFramebuffer(void* pixels, size_t pitch_bytes) {
+    check(srt_read_framebuffer(ctx_, pixels, pitch_bytes, row_begin_, row_end_), "srt_read_framebuffer");
+}
+
+std::vector<float> PathTraceRenderer::ReadAccumulator() {
+    std::vector<float> out((size_t)width_ * height_ * 4);
+    check(srt_read_accumulator(ctx_, out.data()), "srt_read_accumulator");
+    return out;
+}
+
+}  // namespace srt_host

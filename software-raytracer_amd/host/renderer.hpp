@@ -1,0 +1,113 @@
+// renderer.hpp — host C++ that owns camera, settings and the progressive-sample state and
+// drives the C-ABI (include/srt_pathtrace.h).  It stands where the reference's main loop
+// stands relative to its workers (Raytracer/Raytracer.cpp:329-342, 373-384, 572-595).
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "scene.hpp"
+#include "srt_pathtrace.h"
+
+namespace srt_host {
+
+struct Vec3 {  // the members of Common.hpp's float3 that Transform uses
+    float x = 0, y = 0, z = 0;
+    Vec3() = default;
+    Vec3(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {}
+    Vec3 operator+(const Vec3& o) const { return {x + o.x, y + o.y, z + o.z}; }
+    Vec3 operator-(const Vec3& o) const { return {x - o.x, y - o.y, z - o.z}; }
+    Vec3 operator*(float s) const { return {x * s, y * s, z * s}; }  // float3 * float3(s)
+    static float Dot(const Vec3& l, const Vec3& r) { return (l.x * r.x + l.y * r.y + l.z * r.z); }
+    static Vec3 Cross(const Vec3& l, const Vec3& r) {  // Common.hpp:94-96
+        return {l.y * r.z - r.y * l.z, r.x * l.z - l.x * r.z, l.x * r.y - r.x * l.y};
+    }
+};
+
+// Transform (Common.hpp:281-292)
+struct Transform {
+    Vec3 right{1, 0, 0};
+    Vec3 up{0, 1, 0};
+    Vec3 forward{0, 0, 1};
+    Vec3 position{0, 0, 0};
+    Vec3 scale{1, 1, 1};
+    // Rodrigues rotation of the three basis vectors (Common.hpp:287-291)
+    void RotateAboutAxis(float angle, Vec3 axis) {
+        forward = forward * cosf(angle) + Vec3::Cross(axis, forward) * sinf(angle) + axis * Vec3::Dot(axis, forward) * (1 - cosf(angle));
+        up = up * cosf(angle) + Vec3::Cross(axis, up) * sinf(angle) + axis * Vec3::Dot(axis, up) * (1 - cosf(angle));
+        right = right * cosf(angle) + Vec3::Cross(axis, right) * sinf(angle) + axis * Vec3::Dot(axis, right) * (1 - cosf(angle));
+    }
+};
+
+class RendererError : public std::runtime_error {
+   public:
+    RendererError(int code, const std::string& m) : std::runtime_error(m), code_(code) {}
+    int code() const { return code_; }
+
+   private:
+    int code_;
+};
+
+// One GPU, one image (or one row band of it).
+class PathTraceRenderer {
+   public:
+    // the reference's mutable globals (Raytracer.cpp:31-34) as members
+    int FOV = 55;
+    int MAXBOUNCES = 2;
+    int TARGETFRAMES = 4096;
+    int ACCUMULATIONFRAMES = 1;
+    uint32_t seed = 0;  // the reference only ever names srand(0) (:263)
+    Transform camera;   // :295-297
+
+    PathTraceRenderer(int device, int width, int height);
+    ~PathTraceRenderer();
+    PathTraceRenderer(const PathTraceRenderer&) = delete;
+    PathTraceRenderer& operator=(const PathTraceRenderer&) = delete;
+
+    int width() const { return width_; }
+    int height() const { return height_; }
+    srt_context* handle() { return ctx_; }
+
+    // ObjectsToRender = scene.GetObjects(); doSetFrame = true   (:293, :421-423)
+    void SetScene(const Scene& scene);
+    void SetEnvironment(const srt_environment& env);
+    // restrict rendering to memory rows [begin,end) (multi-GPU row stripes)
+    void SetRowBand(int begin, int end);
+    // doSetFrame = true: any camera / object / setting edit (:391,453,461,469,476,497,522)
+    void Invalidate() { doSetFrame_ = true; }
+
+    // One pass of the frame loop's accumulate state machine (:572-595), path-trace mode,
+    // followed by releasing the workers for ONE frame.  Reproduces the reference's sample
+    // indices and setFrame flags including its quirk: after an edit the first full
+    // resolution frame is rendered with setFrame == true AND ACCUMULATIONFRAMES == 2.
+    // (The 1/4-resolution frame the reference shows first is the "progressive blocks" row
+    // of SURVEY §8f and is not rendered.)  Returns false when nothing was launched
+    // (ACCUMULATIONFRAMES == TARGETFRAMES, :572-574).
+    bool RenderFrame();
+
+    // Clean sequence used by benchmarks and fixtures: `count` further samples in ONE
+    // launch; the first call after Invalidate() starts at sample 1 with reset.
+    void RenderSamples(uint32_t count, bool count_rays = false);
+
+    void Wait();
+    bool Done();
+    srt_stats Stats();
+    // blit: copy the band into an SDL-surface-like buffer (renderSurface->pixels, :64)
+    void ReadFramebuffer(void* pixels, size_t pitch_bytes);
+    std::vector<float> ReadAccumulator();
+
+   private:
+    void check(int rc, const char* what);
+    void push_camera();
+    srt_context* ctx_ = nullptr;
+    int width_, height_;
+    int row_begin_, row_end_;
+    bool doSetFrame_ = true;  // a fresh renderer starts like the app after its first edit
+    bool ui_after_reset_ = false;
+    uint32_t next_clean_sample_ = 1;
+};
+
+}  // namespace srt_host
