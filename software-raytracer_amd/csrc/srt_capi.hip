@@ -195,7 +195,8 @@ int srt_set_scene(srt_context* ctx, const srt_object* objects, size_t count) {
         else if (objects[i].type != SRT_OBJ_NONE)
             return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: object %zu has unknown type %d", i, objects[i].type);
     }
-    const int nvec = ns + 2 * nb + 3 * (ns + nb);
+    const int ns4 = (ns + 3) & ~3;  // sphere block padded for the 4-wide scan
+    const int nvec = ns4 + 2 * nb + 3 * (ns + nb);
     if ((size_t)nvec * sizeof(float4) > (size_t)ctx->lds_limit_bytes)
         return fail(ctx, SRT_ERR_INVALID_ARG,
                     "srt_set_scene: %d spheres + %d boxes need %zu B of LDS, limit %d B (tile streaming not built yet)", ns, nb,
@@ -204,7 +205,8 @@ int srt_set_scene(srt_context* ctx, const srt_object* objects, size_t count) {
     SRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->h_scene.assign((size_t)(nvec > 0 ? nvec : 1), make_float4(0, 0, 0, 0));
     float4* sph = ctx->h_scene.data();
-    float4* box = sph + ns;
+    for (int i = ns; i < ns4; ++i) sph[i] = make_float4(0, 0, 0, -1.0f);  // d2 > r*r always: never a candidate
+    float4* box = sph + ns4;
     float4* mat = box + 2 * nb;
     int is = 0, ib = 0;
     for (size_t i = 0; i < count; ++i) {

@@ -39,9 +39,10 @@
 namespace srt {
 
 // ---- device scene image (identical bytes in HBM and in LDS) ----------------------
-// float4 units:  [0 .. ns)                      sphere  (cx, cy, cz, r*r)
-//                [ns .. ns+2nb)                 box     (cx, cy, cz, _), (hx, hy, hz, _)
-//                [ns+2nb .. ns+2nb+3(ns+nb))    material rows, primitive order:
+// float4 units (ns4 = ns rounded up to a multiple of 4):
+//                [0 .. ns4)                     sphere  (cx, cy, cz, r*r); pad = (0,0,0,-1)
+//                [ns4 .. ns4+2nb)               box     (cx, cy, cz, _), (hx, hy, hz, _)
+//                [ns4+2nb .. +3(ns+nb))         material rows, primitive order:
 //                     (smoothness, specular_amount, base.r, base.g)
 //                     (base.b, emissive.r, emissive.g, emissive.b)
 //                     (specular.r, specular.g, specular.b, bits(list index))
@@ -87,10 +88,11 @@ __device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.
 struct Lds {
     const float4* v;  // LDS base
     int ns, nb;
+    __device__ __forceinline__ int ns4() const { return (ns + 3) & ~3; }
     __device__ __forceinline__ float4 sphere(int j) const { return v[j]; }
-    __device__ __forceinline__ float4 box_c(int j) const { return v[ns + 2 * j]; }
-    __device__ __forceinline__ float4 box_h(int j) const { return v[ns + 2 * j + 1]; }
-    __device__ __forceinline__ float4 mat(int p, int row) const { return v[ns + 2 * nb + 3 * p + row]; }
+    __device__ __forceinline__ float4 box_c(int j) const { return v[ns4() + 2 * j]; }
+    __device__ __forceinline__ float4 box_h(int j) const { return v[ns4() + 2 * j + 1]; }
+    __device__ __forceinline__ float4 mat(int p, int row) const { return v[ns4() + 2 * nb + 3 * p + row]; }
 };
 
 // sign(float3) component (Common.hpp:328-333): t != 0 ? t / abs(t) : 0
@@ -144,22 +146,32 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, V3 o, V3 d) {
     float best = __builtin_inff();
     int bp = -1;
     const int ns = S.ns, nb = S.nb;
-    for (int j = 0; j < ns; ++j) {
-        const float4 s = S.sphere(j);
+    // The sphere list is padded to a multiple of 4 with never-hit dummies (r*r = -1), so
+    // four broadcast ds_read_b128 are issued back to back and their latency overlaps the
+    // arithmetic of the previous spheres.
+    auto test = [&](const float4 s, int j) {
         // Sphere::line_sphere_intersection (Object.hpp:104-141)
-        float Lx = s.x - o.x, Ly = s.y - o.y, Lz = s.z - o.z;  // :115
-        float tc = fabsf((Lx * d.x + Ly * d.y) + Lz * d.z);    // :118-119
+        float Lx = s.x - o.x, Ly = s.y - o.y, Lz = s.z - o.z;                 // :115
+        float tc = fabsf((Lx * d.x + Ly * d.y) + Lz * d.z);                   // :118-119
         float qx = d.x * tc + o.x, qy = d.y * tc + o.y, qz = d.z * tc + o.z;  // :121
-        float ex = qx - s.x, ey = qy - s.y, ez = qz - s.z;     // :124
-        float d2 = (ex * ex + ey * ey) + ez * ez;              // :125
-        bool cand = !(d2 > s.w);                                // :127
-        if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {        // wave-uniform skip
-            float t1 = tc - sqrtf(s.w - d2);                    // :131-133
-            if (cand && t1 < best) {                            // Raytracer.cpp:130-132
+        float ex = qx - s.x, ey = qy - s.y, ez = qz - s.z;                    // :124
+        float d2 = (ex * ex + ey * ey) + ez * ez;                             // :125
+        bool cand = !(d2 > s.w);                                              // :127
+        if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {                      // wave-uniform skip
+            float t1 = tc - sqrtf(s.w - d2);                                  // :131-133
+            if (cand && t1 < best) {                                          // Raytracer.cpp:130-132
                 best = t1;
                 bp = j;
             }
         }
+    };
+    const int ns4 = (ns + 3) & ~3;
+    for (int j = 0; j < ns4; j += 4) {
+        const float4 s0 = S.v[j], s1 = S.v[j + 1], s2 = S.v[j + 2], s3 = S.v[j + 3];
+        test(s0, j);
+        test(s1, j + 1);
+        test(s2, j + 2);
+        test(s3, j + 3);
     }
     Hit h;
     V3 bt1 = v3(0, 0, 0);

@@ -1,0 +1,198 @@
+"""GPU tests of everything around the kernel: row bands, resume, external output buffers,
+the C++ host renderer's frame sequences, full-size (BASELINE) properties."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import scene_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _pt(srt, name, w, h):
+    s = srt.host.Scene(scene_path(name))
+    objs, n = s.objects_copy()
+    pt = srt.PathTracer(w, h)
+    pt.set_scene(objs, n)
+    pt.set_camera(srt.default_camera())
+    return pt, objs, n
+
+
+def _oracle_frame(oracle, objs, n, w, h, **kw):
+    return oracle.render(C.cast(objs, C.POINTER(oracle.Object)), n, oracle.default_environment(), oracle.default_camera(), w, h, **kw)
+
+
+def test_row_bands_concatenate_to_the_full_frame(srt):
+    """Any partition into memory-row bands reproduces the single-launch frame byte for byte
+    (RNG keyed by absolute pixel) — the multi-GPU contract, exercised on one GPU."""
+    w, h = 200, 117
+    pt, objs, n = _pt(srt, "Scene_indirect", w, h)
+    pt.render(spp=3, bounces=8, seed=5)
+    full_fb, full_acc = pt.framebuffer(), pt.accumulator()
+    pt2 = srt.PathTracer(w, h)
+    pt2.set_scene(objs, n)
+    pt2.set_camera(srt.default_camera())
+    for rb, re in [(0, 1), (1, 16), (16, 17), (17, 100), (100, 117)]:  # ragged, not multiples of the tile
+        pt2.render(spp=3, bounces=8, seed=5, rows=(rb, re))
+        assert np.array_equal(pt2.framebuffer(rows=(rb, re)), full_fb[rb:re])
+    assert np.array_equal(pt2.framebuffer(), full_fb)
+    assert np.array_equal(pt2.accumulator().view(np.uint32), full_acc.view(np.uint32))
+
+
+def test_resume_equals_one_shot_and_oracle(srt, oracle):
+    w, h = 96, 64
+    pt, objs, n = _pt(srt, "Scene2", w, h)
+    pt.render(spp=7, bounces=4, seed=3)
+    one = (pt.framebuffer(), pt.accumulator())
+    pt.render(spp=2, bounces=4, seed=3, first_sample=1, reset=True)
+    pt.render(spp=1, bounces=4, seed=3, first_sample=3, reset=False)
+    pt.render(spp=4, bounces=4, seed=3, first_sample=4, reset=False)
+    assert np.array_equal(pt.framebuffer(), one[0])
+    assert np.array_equal(pt.accumulator().view(np.uint32), one[1].view(np.uint32))
+    ofb, oacc, _ = _oracle_frame(oracle, objs, n, w, h, spp=7, bounces=4, seed=3)
+    assert np.array_equal(one[0], ofb) and np.array_equal(one[1].view(np.uint32), oacc.view(np.uint32))
+
+
+def test_write_accumulator_then_resume(srt, oracle):
+    """Accumulator upload (incl. a non-zero alpha) continues exactly like the oracle."""
+    w, h = 48, 40
+    pt, objs, n = _pt(srt, "Scene1", w, h)
+    rng = np.random.default_rng(1)
+    acc0 = rng.random((h, w, 4), dtype=np.float32) * 3
+    pt.write_accumulator(acc0)
+    pt.render(spp=2, bounces=3, seed=9, first_sample=5, reset=False)
+    ofb, oacc, _ = _oracle_frame(oracle, objs, n, w, h, spp=2, bounces=3, seed=9, first_sample=5, reset=False, accumulator=acc0)
+    assert np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32))
+    assert np.array_equal(pt.framebuffer(), ofb)
+    assert ((pt.framebuffer() >> 24) == 255).all()  # a/(0+a) = 1 -> alpha byte 255
+
+
+def test_bind_output_renders_into_caller_memory(srt):
+    import torch
+
+    w, h = 64, 32
+    pt, objs, n = _pt(srt, "Scene3", w, h)
+    pt.render(spp=2, bounces=2, seed=0)
+    own = pt.framebuffer()
+    t = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    pt.bind_output(d_framebuffer=t.data_ptr())
+    pt.render(spp=2, bounces=2, seed=0)
+    pt.wait()
+    assert np.array_equal(t.cpu().numpy().view(np.uint32), own)
+    pt.bind_output()
+
+
+def test_edge_cases_empty_scene_and_errors(srt, oracle):
+    w, h = 33, 17
+    pt = srt.PathTracer(w, h)
+    with pytest.raises(srt.SrtError) as e:
+        pt.render()
+    assert e.value.code == srt.capi.ERR_STATE
+    pt.set_scene((srt.Object * 1)(), 0)  # empty ObjectsToRender: every pixel is sky
+    pt.set_camera(srt.default_camera())
+    pt.render(spp=2, bounces=8, seed=0, count_rays=True)
+    arr, n = oracle.make_objects([])
+    ofb, oacc, orays = oracle.render(arr, 0, oracle.default_environment(), oracle.default_camera(), w, h, spp=2, bounces=8, seed=0)
+    assert np.array_equal(pt.framebuffer(), ofb) and pt.stats().rays == orays == w * h * 2
+    for bad in [dict(rows=(5, 5)), dict(rows=(0, h + 1)), dict(spp=0), dict(first_sample=0), dict(bounces=-1)]:
+        with pytest.raises(srt.SrtError):
+            pt.render(**bad)
+    assert pt.poll() in (True, False)
+    pt.wait()
+    assert pt.poll() is True
+    # inert objects keep list slots but never hit; a box before a coincident sphere wins the tie
+    objs = [dict(type=oracle.OBJ_NONE, position=(0, 0, 3)),
+            dict(type=oracle.OBJ_SPHERE, position=(0.3, 0.2, 6), radius=1.5, emissive=(1, 0, 0)),
+            dict(type=oracle.OBJ_BOX, position=(0.3, 0.2, 6), half_size=(1, 1, 1), emissive=(0, 1, 0)),
+            dict(type=oracle.OBJ_BOX, position=(0.3, 0.2, 6), half_size=(1, 1, 1), emissive=(0, 0, 1))]
+    arr, n = oracle.make_objects(objs)
+    pt.set_scene(C.cast(arr, C.POINTER(srt.Object)), n)
+    pt.render(spp=2, bounces=3, seed=1)
+    ofb, oacc, _ = oracle.render(arr, n, oracle.default_environment(), oracle.default_camera(), w, h, spp=2, bounces=3, seed=1)
+    assert np.array_equal(pt.framebuffer(), ofb) and np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32))
+
+
+def test_camera_moved_and_rotated(srt, oracle):
+    w, h = 120, 80
+    pt, objs, n = _pt(srt, "Scene_indirect", w, h)
+    basis = srt.host.rotate_about_axis([1, 0, 0, 0, 1, 0, 0, 0, 1], 0.4, (0, 1, 0))
+    basis = srt.host.rotate_about_axis(basis, -0.15, basis[0:3])
+    cam = srt.Camera()
+    cam.position = (C.c_float * 3)(0.5, 0.3, -1.0)
+    cam.right, cam.up, cam.forward = (C.c_float * 3)(*basis[0:3]), (C.c_float * 3)(*basis[3:6]), (C.c_float * 3)(*basis[6:9])
+    cam.fov_degrees = 90
+    pt.set_camera(cam)
+    pt.render(spp=2, bounces=6, seed=2)
+    ocam = oracle.Camera.from_buffer_copy(bytes(cam))
+    ofb, oacc, _ = oracle.render(C.cast(objs, C.POINTER(oracle.Object)), n, oracle.default_environment(), ocam, w, h, spp=2, bounces=6, seed=2)
+    assert np.array_equal(pt.framebuffer(), ofb) and np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32))
+
+
+def test_custom_environment(srt, oracle):
+    w, h = 64, 64
+    pt, objs, n = _pt(srt, "Scene1", w, h)
+    env = srt.default_environment()
+    env.sky_color = (C.c_float * 3)(0.1, 0.2, 0.9)
+    env.sun_direction = (C.c_float * 3)(0.0, -0.6, 0.8)
+    env.sun_color = (C.c_float * 3)(30, 20, 10)
+    pt.set_environment(env)
+    pt.render(spp=2, bounces=4, seed=0)
+    oenv = oracle.Environment.from_buffer_copy(bytes(env))
+    ofb, oacc, _ = oracle.render(C.cast(objs, C.POINTER(oracle.Object)), n, oenv, oracle.default_camera(), w, h, spp=2, bounces=4, seed=0)
+    assert np.array_equal(pt.framebuffer(), ofb) and np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32))
+
+
+def test_host_renderer_sequences(srt, oracle):
+    """C++ PathTraceRenderer: the clean sequence and the reference's UI sequence
+    (Raytracer.cpp:572-590: first full frame after an edit has setFrame AND ACC == 2)."""
+    w, h = 80, 60
+    scene = srt.host.Scene(scene_path("Scene3_indirect"))
+    objs, n = scene.objects_copy()
+    r = srt.host.Renderer(w, h)
+    r.settings(fov=55, max_bounces=3, target_frames=6, seed=4)
+    r.set_scene(scene)
+    r.render_samples(2)
+    r.render_samples(3, count_rays=True)
+    ofb, oacc, _ = _oracle_frame(oracle, objs, n, w, h, spp=5, bounces=3, seed=4)
+    assert np.array_equal(r.framebuffer(), ofb) and np.array_equal(r.accumulator().view(np.uint32), oacc.view(np.uint32))
+    assert r.accumulation_frames == 5 and r.stats().path_samples == w * h * 3
+    # UI sequence: edit -> frames f=2 (reset), 3, 4, 5, 6 then stop at TARGETFRAMES
+    r.invalidate()
+    launched = 0
+    while r.render_frame():
+        launched += 1
+    assert launched == 5 and r.accumulation_frames == 6 and not r.render_frame()
+    _, oacc, _ = _oracle_frame(oracle, objs, n, w, h, spp=1, bounces=3, seed=4, first_sample=2, reset=True)
+    ofb, oacc, _ = _oracle_frame(oracle, objs, n, w, h, spp=4, bounces=3, seed=4, first_sample=3, reset=False, accumulator=oacc)
+    assert np.array_equal(r.framebuffer(), ofb) and np.array_equal(r.accumulator().view(np.uint32), oacc.view(np.uint32))
+    # row band through the host class
+    r.set_band(10, 30)
+    r.render_samples(2)
+    ofb2, _, _ = _oracle_frame(oracle, objs, n, w, h, spp=2, bounces=3, seed=4)
+    assert np.array_equal(r.framebuffer(), ofb2[10:30])
+    r.close()
+
+
+def test_full_size_properties_1080p(srt, oracle):
+    """BASELINE configs[1] size. Oracle compare at 1 spp (seconds on the host cores), then
+    size-independent properties at the full 32 spp: determinism across launches, band
+    concatenation, resume == one-shot."""
+    w, h = 1920, 1080
+    pt, objs, n = _pt(srt, "Scene1", w, h)
+    pt.render(spp=1, bounces=8, seed=0, count_rays=True)
+    fb1 = pt.framebuffer()
+    ofb, oacc, orays = _oracle_frame(oracle, objs, n, w, h, spp=1, bounces=8, seed=0, threads=16)
+    assert np.array_equal(fb1, ofb) and pt.stats().rays == orays
+    assert np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32))
+    pt.render(spp=32, bounces=8, seed=0)
+    a = pt.framebuffer()
+    pt.render(spp=32, bounces=8, seed=0)
+    assert np.array_equal(pt.framebuffer(), a)  # deterministic
+    for rb, re in [(0, 135), (135, 600), (600, 1080)]:
+        pt.render(spp=32, bounces=8, seed=0, rows=(rb, re))
+        assert np.array_equal(pt.framebuffer(rows=(rb, re)), a[rb:re])
+    pt.render(spp=20, bounces=8, seed=0)
+    pt.render(spp=12, bounces=8, seed=0, first_sample=21, reset=False)
+    assert np.array_equal(pt.framebuffer(), a)
+    assert (a >> 24 == 0).all()  # alpha byte is always 0 (Raytracer.cpp:74)
