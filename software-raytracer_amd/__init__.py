@@ -11,6 +11,14 @@ if the HIP library is missing or no GPU is present, calls fail loudly.
 The directory name has a hyphen, so import it with
     importlib.import_module("software-raytracer_amd")
 """
+# torch bundles its own libamdhip64 (same soname as /opt/rocm's).  Import it before any native
+# library of this package is dlopen-ed so that the process ends up with ONE HIP runtime that
+# torch tensors, streams and our kernels share.  (The C++ host / CLI never involve torch.)
+try:
+    import torch  # noqa: F401
+except ImportError:  # plumbing only; the native libraries work without it
+    pass
+
 from . import capi  # noqa: F401
 from .capi import (  # noqa: F401
     Camera,
