@@ -47,6 +47,18 @@ def algorithmic_laneops_per_sample(rbar, n_sph, n_box):
     return rbar * (24 * n_sph + 35 * n_box) + 60 * rbar + 30
 
 
+def host_cpu_share():
+    """CPUs this process may actually use: min(affinity, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,7 +249,7 @@ def main():
         import numpy as np
         import srt_oracle_py as O
 
-        cores = os.cpu_count() or 1
+        cores = host_cpu_share()
         cspp = args.cpu_spp
         oarr = C.cast(objs, C.POINTER(O.Object))
         t1 = time.perf_counter()
