@@ -12,12 +12,12 @@
  *
  *  2. powf.  GetEnvironmentColor calls powf (Raytracer.cpp:81,87).  MSVC UCRT, glibc
  *     and ROCm OCML disagree in the last ulp, so a bit-exact GPU/CPU comparison needs
- *     ONE definition.  srt_powf below uses only IEEE-754 double +,-,*,/ and integer
- *     bit operations in a fixed order, so it gives identical bits on x86 and gfx950
+ *     ONE definition.  srt_powf below uses only IEEE-754 double +,-,*,/, explicit fma and
+ *     integer bit operations in a fixed order, so it gives identical bits on x86 and gfx950
  *     provided the translation unit is compiled with -ffp-contract=off.  It is
  *     faithfully rounded (tests bound it to <= 1 ulp of libm's powf).
  *
- * Plain C99 / C++ / HIP. No libm dependency.
+ * Plain C99 / C++ / HIP.  The only libm symbol used on the host is fma().
  */
 #ifndef SRT_DEFS_H
 #define SRT_DEFS_H
@@ -62,6 +62,20 @@ SRT_HD uint32_t srt_rng_draw(uint32_t key, uint32_t draw) {
 
 /* ---- portable powf --------------------------------------------------------------- */
 
+/* Explicit fused multiply-add in double.  IEEE-754 fma is correctly rounded, so libm's
+ * fma() on the host and v_fma_f64 on gfx950 give the same bits; this is NOT implicit
+ * contraction (the translation units are still compiled with -ffp-contract=off). */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SRT_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#else
+#ifdef __cplusplus
+extern "C" double fma(double, double, double);
+#else
+double fma(double, double, double);
+#endif
+#define SRT_FMA(a, b, c) fma((a), (b), (c))
+#endif
+
 typedef union srt_f64bits {
     double d;
     uint64_t u;
@@ -100,22 +114,22 @@ SRT_HD float srt_powf(float xf, float yf) {
     double s = (m - 1.0) / (m + 1.0);
     double z = s * s;
     double p = 1.0 / 23.0;
-    p = p * z + 1.0 / 21.0;
-    p = p * z + 1.0 / 19.0;
-    p = p * z + 1.0 / 17.0;
-    p = p * z + 1.0 / 15.0;
-    p = p * z + 1.0 / 13.0;
-    p = p * z + 1.0 / 11.0;
-    p = p * z + 1.0 / 9.0;
-    p = p * z + 1.0 / 7.0;
-    p = p * z + 1.0 / 5.0;
-    p = p * z + 1.0 / 3.0;
-    p = p * z + 1.0;
+    p = SRT_FMA(p, z, 1.0 / 21.0);
+    p = SRT_FMA(p, z, 1.0 / 19.0);
+    p = SRT_FMA(p, z, 1.0 / 17.0);
+    p = SRT_FMA(p, z, 1.0 / 15.0);
+    p = SRT_FMA(p, z, 1.0 / 13.0);
+    p = SRT_FMA(p, z, 1.0 / 11.0);
+    p = SRT_FMA(p, z, 1.0 / 9.0);
+    p = SRT_FMA(p, z, 1.0 / 7.0);
+    p = SRT_FMA(p, z, 1.0 / 5.0);
+    p = SRT_FMA(p, z, 1.0 / 3.0);
+    p = SRT_FMA(p, z, 1.0);
     double lnm = 2.0 * s * p;
     const double LN2_HI = 6.93147180369123816490e-01; /* 0x3fe62e42fee00000 */
     const double LN2_LO = 1.90821492927058770002e-10; /* 0x3dea39ef35793c76 */
     double ed = (double)e;
-    double lnx = ed * LN2_HI + (lnm + ed * LN2_LO);
+    double lnx = SRT_FMA(ed, LN2_HI, SRT_FMA(ed, LN2_LO, lnm));
     double t = (double)yf * lnx;
 
     /* e^t = 2^k * e^r */
@@ -128,21 +142,21 @@ SRT_HD float srt_powf(float xf, float yf) {
     double kd = t * 1.44269504088896338700e+00;
     int k = (int)(kd < 0.0 ? kd - 0.5 : kd + 0.5);
     double kk = (double)k;
-    double r = (t - kk * LN2_HI) - kk * LN2_LO;
+    double r = SRT_FMA(-kk, LN2_LO, SRT_FMA(-kk, LN2_HI, t));
     double q = 1.0 / 6227020800.0; /* 1/13! */
-    q = q * r + 1.0 / 479001600.0;
-    q = q * r + 1.0 / 39916800.0;
-    q = q * r + 1.0 / 3628800.0;
-    q = q * r + 1.0 / 362880.0;
-    q = q * r + 1.0 / 40320.0;
-    q = q * r + 1.0 / 5040.0;
-    q = q * r + 1.0 / 720.0;
-    q = q * r + 1.0 / 120.0;
-    q = q * r + 1.0 / 24.0;
-    q = q * r + 1.0 / 6.0;
-    q = q * r + 0.5;
-    q = q * r + 1.0;
-    q = q * r + 1.0;
+    q = SRT_FMA(q, r, 1.0 / 479001600.0);
+    q = SRT_FMA(q, r, 1.0 / 39916800.0);
+    q = SRT_FMA(q, r, 1.0 / 3628800.0);
+    q = SRT_FMA(q, r, 1.0 / 362880.0);
+    q = SRT_FMA(q, r, 1.0 / 40320.0);
+    q = SRT_FMA(q, r, 1.0 / 5040.0);
+    q = SRT_FMA(q, r, 1.0 / 720.0);
+    q = SRT_FMA(q, r, 1.0 / 120.0);
+    q = SRT_FMA(q, r, 1.0 / 24.0);
+    q = SRT_FMA(q, r, 1.0 / 6.0);
+    q = SRT_FMA(q, r, 0.5);
+    q = SRT_FMA(q, r, 1.0);
+    q = SRT_FMA(q, r, 1.0);
     /* scale by 2^k in two exact steps so that the only rounding is the final
      * double->float conversion (also correct when the float result is subnormal). */
     srt_f64bits sc;

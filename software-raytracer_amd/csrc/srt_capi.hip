@@ -8,12 +8,14 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
 #include <vector>
 
 #include "srt_kernel.hip.h"
+#include "srt_scene_image.h"
 #include "srt_pathtrace.h"
 
 namespace {
@@ -36,11 +38,12 @@ struct srt_context {
     bool launched = false;
 
     // device buffers
-    float4* d_scene = nullptr;
-    size_t scene_capacity_vec4 = 0;
-    int scene_vec4 = 0, ns = 0, nb = 0;
+    // two images of the same scene: [0] clustered (default), [1] plain brute force (A/B aid)
+    float4* d_scene[2] = {nullptr, nullptr};
+    size_t scene_capacity_vec4[2] = {0, 0};
+    srt::SceneLayout layout[2];
     bool scene_set = false;
-    std::vector<float4> h_scene;  // staging for the async upload
+    std::vector<float4> h_scene[2];  // staging for the async upload
 
     uint32_t* d_fb_own = nullptr;
     float4* d_acc_own = nullptr;
@@ -55,6 +58,7 @@ struct srt_context {
     uint64_t pending_samples = 0;
     bool count_rays = false;
     int lds_limit_bytes = 64 * 1024;
+    int variant = -1;  // >= 0 overrides SRT_KERNEL (set through srt_debug_set_variant)
 
     char error[512] = "";
 };
@@ -170,7 +174,8 @@ int srt_destroy(srt_context* ctx) {
     if (!ctx) return SRT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->d_scene) (void)hipFree(ctx->d_scene);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->d_scene[i]) (void)hipFree(ctx->d_scene[i]);
     if (ctx->d_fb_own) (void)hipFree(ctx->d_fb_own);
     if (ctx->d_acc_own) (void)hipFree(ctx->d_acc_own);
     if (ctx->d_rays) (void)hipFree(ctx->d_rays);
@@ -186,63 +191,30 @@ int srt_set_scene(srt_context* ctx, const srt_object* objects, size_t count) {
     if (count && !objects) return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: objects is NULL");
     if (count > 0x3fffffff) return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: too many objects");
     SRT_HIP(ctx, hipSetDevice(ctx->device));
-    int ns = 0, nb = 0;
     for (size_t i = 0; i < count; ++i) {
-        if (objects[i].type == SRT_OBJ_SPHERE)
-            ++ns;
-        else if (objects[i].type == SRT_OBJ_BOX)
-            ++nb;
-        else if (objects[i].type != SRT_OBJ_NONE)
-            return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: object %zu has unknown type %d", i, objects[i].type);
+        int t = objects[i].type;
+        if (t != SRT_OBJ_SPHERE && t != SRT_OBJ_BOX && t != SRT_OBJ_NONE)
+            return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: object %zu has unknown type %d", i, t);
     }
-    const int ns4 = (ns + 3) & ~3;  // sphere block padded for the 4-wide scan
-    const int nvec = ns4 + 2 * nb + 3 * (ns + nb);
-    if ((size_t)nvec * sizeof(float4) > (size_t)ctx->lds_limit_bytes)
-        return fail(ctx, SRT_ERR_INVALID_ARG,
-                    "srt_set_scene: %d spheres + %d boxes need %zu B of LDS, limit %d B (tile streaming not built yet)", ns, nb,
-                    (size_t)nvec * sizeof(float4), ctx->lds_limit_bytes);
     // the previous upload may still be in flight from h_scene
     SRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->h_scene.assign((size_t)(nvec > 0 ? nvec : 1), make_float4(0, 0, 0, 0));
-    float4* sph = ctx->h_scene.data();
-    for (int i = ns; i < ns4; ++i) sph[i] = make_float4(0, 0, 0, -1.0f);  // d2 > r*r always: never a candidate
-    float4* box = sph + ns4;
-    float4* mat = box + 2 * nb;
-    int is = 0, ib = 0;
-    for (size_t i = 0; i < count; ++i) {
-        const srt_object& o = objects[i];
-        int p;
-        if (o.type == SRT_OBJ_SPHERE) {
-            // squaredRadius = sphereRadius * sphereRadius   (Object.hpp:122)
-            sph[is] = make_float4(o.position[0], o.position[1], o.position[2], o.radius * o.radius);
-            p = is++;
-        } else if (o.type == SRT_OBJ_BOX) {
-            box[2 * ib] = make_float4(o.position[0], o.position[1], o.position[2], 0.0f);
-            box[2 * ib + 1] = make_float4(o.half_size[0], o.half_size[1], o.half_size[2], 0.0f);
-            p = ns + ib++;
-        } else {
-            continue;  // inert Object: Raytrace() is never valid (Object.hpp:21-23)
+    static const bool no_cluster = getenv("SRT_NO_CLUSTER") != nullptr;
+    for (int v = 0; v < 2; ++v) {
+        srt::SceneLayout L = srt::build_scene_image(objects, count, v == 0 && !no_cluster, ctx->h_scene[v]);
+        if ((size_t)L.total_vec4 * sizeof(float4) + srt::WG_SCRATCH_BYTES > (size_t)ctx->lds_limit_bytes || count >= 32768)
+            return fail(ctx, SRT_ERR_INVALID_ARG,
+                        "srt_set_scene: %d spheres + %d boxes need %zu B of LDS, limit %d B (tile streaming not built yet)",
+                        L.n_spheres, L.nb, (size_t)L.total_vec4 * sizeof(float4), ctx->lds_limit_bytes);
+        if (ctx->h_scene[v].size() > ctx->scene_capacity_vec4[v] || !ctx->d_scene[v]) {
+            if (ctx->d_scene[v]) SRT_HIP(ctx, hipFree(ctx->d_scene[v]));
+            ctx->d_scene[v] = nullptr;
+            SRT_HIP(ctx, hipMalloc((void**)&ctx->d_scene[v], ctx->h_scene[v].size() * sizeof(float4)));
+            ctx->scene_capacity_vec4[v] = ctx->h_scene[v].size();
         }
-        const srt_material& m = o.material;
-        float ord;
-        int32_t idx = (int32_t)i;
-        memcpy(&ord, &idx, 4);
-        mat[3 * p + 0] = make_float4(m.smoothness, m.specular_amount, m.base_color[0], m.base_color[1]);
-        mat[3 * p + 1] = make_float4(m.base_color[2], m.emissive_color[0], m.emissive_color[1], m.emissive_color[2]);
-        mat[3 * p + 2] = make_float4(m.specular_color[0], m.specular_color[1], m.specular_color[2], ord);
+        SRT_HIP(ctx, hipMemcpyAsync(ctx->d_scene[v], ctx->h_scene[v].data(), ctx->h_scene[v].size() * sizeof(float4),
+                                    hipMemcpyHostToDevice, ctx->stream));
+        ctx->layout[v] = L;
     }
-    if ((size_t)nvec > ctx->scene_capacity_vec4 || !ctx->d_scene) {
-        if (ctx->d_scene) SRT_HIP(ctx, hipFree(ctx->d_scene));
-        ctx->d_scene = nullptr;
-        size_t cap = (size_t)(nvec > 0 ? nvec : 1);
-        SRT_HIP(ctx, hipMalloc((void**)&ctx->d_scene, cap * sizeof(float4)));
-        ctx->scene_capacity_vec4 = cap;
-    }
-    SRT_HIP(ctx, hipMemcpyAsync(ctx->d_scene, ctx->h_scene.data(), ctx->h_scene.size() * sizeof(float4), hipMemcpyHostToDevice,
-                                ctx->stream));
-    ctx->scene_vec4 = nvec;
-    ctx->ns = ns;
-    ctx->nb = nb;
     ctx->scene_set = true;
     return SRT_OK;
 }
@@ -331,10 +303,23 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     K.max_bounces = p->max_bounces;
     K.seed = p->seed;
     K.flags = p->flags & (SRT_RENDER_RESET | SRT_RENDER_COUNT_RAYS);
-    K.ns = ctx->ns;
-    K.nb = ctx->nb;
-    K.scene_vec4 = ctx->scene_vec4;
-    K.scene = ctx->d_scene;
+    static const int variant = [] {
+        const char* v = getenv("SRT_KERNEL");
+        return v ? atoi(v) : 0;
+    }();
+    const int use = ctx->variant >= 0 ? ctx->variant : variant;
+    const int img = (use == 2) ? 1 : 0;  // variant 2: plain brute-force image
+    const srt::SceneLayout& SL = ctx->layout[img];
+    K.nu4 = SL.nu4;
+    K.nc = SL.nc;
+    K.K = SL.K;
+    K.nsT = SL.nsT;
+    K.nb = SL.nb;
+    K.off_bounds = SL.off_bounds;
+    K.off_box = SL.off_box;
+    K.off_mat = SL.off_mat;
+    K.scene_vec4 = SL.total_vec4;
+    K.scene = ctx->d_scene[img];
     K.accumulator = ctx->d_acc;
     K.framebuffer = ctx->d_fb;
     K.ray_counter = ctx->d_rays;
@@ -344,9 +329,13 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
 
     dim3 grid((unsigned)((W + srt::WG_W - 1) / srt::WG_W), (unsigned)((K.rows + srt::WG_H - 1) / srt::WG_H));
     dim3 block(srt::WG_THREADS);
-    size_t lds_bytes = (size_t)(ctx->scene_vec4 > 0 ? ctx->scene_vec4 : 1) * sizeof(float4);
+    size_t lds_bytes = (size_t)(SL.total_vec4 > 0 ? SL.total_vec4 : 1) * sizeof(float4) + srt::WG_SCRATCH_BYTES;
     SRT_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
-    hipLaunchKernelGGL(srt::pathtrace_kernel, grid, block, lds_bytes, ctx->stream, K);
+    // variants are a development aid for in-process A/B timing; all are bit-identical
+    if (use == 1)
+        hipLaunchKernelGGL(srt::pathtrace_kernel<5>, grid, block, lds_bytes, ctx->stream, K);
+    else
+        hipLaunchKernelGGL(srt::pathtrace_kernel<1>, grid, block, lds_bytes, ctx->stream, K);
     SRT_HIP(ctx, hipGetLastError());
     SRT_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
     ctx->launched = true;
@@ -354,6 +343,24 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     ctx->pending_samples = (uint64_t)W * (uint64_t)K.rows * p->sample_count;
     return SRT_OK;
 }
+
+// Development aid, not part of the public header: pick a kernel tuning variant for A/B
+// timing inside one process.  All variants produce identical bits.
+int srt_debug_set_variant(srt_context* ctx, int variant) {
+    if (!ctx) return SRT_ERR_INVALID_ARG;
+    ctx->variant = variant;
+    return SRT_OK;
+}
+
+#ifdef SRT_STATS
+int srt_debug_read_stats(unsigned long long* out8) {
+    (void)hipDeviceSynchronize();
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(srt::g_stats), 8 * sizeof(unsigned long long));
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(srt::g_stats), z, sizeof z);
+    return e == hipSuccess ? 0 : 3;
+}
+#endif
 
 int srt_wait(srt_context* ctx) {
     if (!ctx) return SRT_ERR_INVALID_ARG;

@@ -38,15 +38,9 @@
 
 namespace srt {
 
-// ---- device scene image (identical bytes in HBM and in LDS) ----------------------
-// float4 units (ns4 = ns rounded up to a multiple of 4):
-//                [0 .. ns4)                     sphere  (cx, cy, cz, r*r); pad = (0,0,0,-1)
-//                [ns4 .. ns4+2nb)               box     (cx, cy, cz, _), (hx, hy, hz, _)
-//                [ns4+2nb .. +3(ns+nb))         material rows, primitive order:
-//                     (smoothness, specular_amount, base.r, base.g)
-//                     (base.b, emissive.r, emissive.g, emissive.b)
-//                     (specular.r, specular.g, specular.b, bits(list index))
-// primitive id p: spheres 0..ns-1 in list order, then boxes ns..ns+nb-1 in list order.
+// ---- device scene image (identical bytes in HBM and in LDS): see srt_scene_image.h ----
+// [0,nu4) uniform spheres | [nu4,nsT) clustered spheres (nc clusters of K) | nc cluster bounds |
+// 2*nb box rows | 3 material rows per primitive id (spheres: index in [0,nsT); boxes: nsT + j).
 struct KernelParams {
     float cam_pos[3];
     float right_rd[3];  // cameraTransform.right * rd          (Raytracer.cpp:114,116)
@@ -59,7 +53,9 @@ struct KernelParams {
     uint32_t first_sample, sample_count;
     int32_t max_bounces;
     uint32_t seed, flags;
-    int32_t ns, nb;
+    // scene image layout (srt_scene_image.h)
+    int32_t nu4, nc, K, nsT, nb;
+    int32_t off_bounds, off_box, off_mat;
     int32_t scene_vec4;  // number of float4 in the scene image
     const float4* scene;
     float4* accumulator;
@@ -71,6 +67,11 @@ constexpr int TILE_W = 8, TILE_H = 8;       // per wavefront
 constexpr int WG_TILES_X = 2, WG_TILES_Y = 2;  // waves per workgroup
 constexpr int WG_THREADS = 64 * WG_TILES_X * WG_TILES_Y;
 constexpr int WG_W = TILE_W * WG_TILES_X, WG_H = TILE_H * WG_TILES_Y;
+// per-wave LDS scratch behind the scene image: work list of (ray lane, cluster) items + one
+// 64-bit result slot per lane (balanced phase 2 of closest_hit)
+constexpr int WORK_MAX = 512;
+constexpr int WAVE_SCRATCH_BYTES = 64 * 8 + WORK_MAX * 2;
+constexpr int WG_SCRATCH_BYTES = WAVE_SCRATCH_BYTES * WG_TILES_X * WG_TILES_Y;
 
 __device__ __forceinline__ float clamp0(float v) { return v < 0 ? 0.0f : v; }  // Common.hpp:254-257
 
@@ -87,12 +88,15 @@ __device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.
 
 struct Lds {
     const float4* v;  // LDS base
-    int ns, nb;
-    __device__ __forceinline__ int ns4() const { return (ns + 3) & ~3; }
-    __device__ __forceinline__ float4 sphere(int j) const { return v[j]; }
-    __device__ __forceinline__ float4 box_c(int j) const { return v[ns4() + 2 * j]; }
-    __device__ __forceinline__ float4 box_h(int j) const { return v[ns4() + 2 * j + 1]; }
-    __device__ __forceinline__ float4 mat(int p, int row) const { return v[ns4() + 2 * nb + 3 * p + row]; }
+    int nu4, nc, K, nsT, nb, off_bounds, off_box, off_mat;
+    unsigned long long* res;  // this wave's 64 result slots
+    unsigned short* work;     // this wave's work list
+    __device__ __forceinline__ float4 sphere(int p) const { return v[p]; }
+    __device__ __forceinline__ float4 bound(int k) const { return v[off_bounds + k]; }
+    __device__ __forceinline__ float4 box_c(int j) const { return v[off_box + 2 * j]; }
+    __device__ __forceinline__ float4 box_h(int j) const { return v[off_box + 2 * j + 1]; }
+    __device__ __forceinline__ float4 mat(int p, int row) const { return v[off_mat + 3 * p + row]; }
+    __device__ __forceinline__ int order(int p) const { return __float_as_int(v[off_mat + 3 * p + 2].w); }
 };
 
 // sign(float3) component (Common.hpp:328-333): t != 0 ? t / abs(t) : 0
@@ -139,58 +143,176 @@ struct Hit {
     V3 n, p;   // normal, point (valid when prim >= 0)
 };
 
-// GetClosestObject (Raytracer.cpp:123-140) over the LDS scene.
-// Strict `<` keeps the lower list index on ties (:132); boxes are scanned after the
-// spheres, so a box additionally wins an exact tie when its list index is lower.
-__device__ __forceinline__ Hit closest_hit(const Lds& S, V3 o, V3 d) {
+// ---- (distance, list index, primitive) packed so that unsigned 64-bit order == the
+// reference's rule "smaller distance wins, equal distance keeps the earlier list entry"
+// (Raytracer.cpp:132).  -0 and +0 compare equal there, so the key uses +0 and keeps the
+// original sign in bit 0.  Bits: [63:32] ordered distance | [31:17] list index | [16:1] prim.
+__device__ __forceinline__ unsigned long long hit_key(float t, int ord, int p) {
+    unsigned u = __float_as_uint(t + 0.0f);
+    u ^= (u & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u;
+    return ((unsigned long long)u << 32) | ((unsigned)ord << 17) | ((unsigned)p << 1) | (__float_as_uint(t) >> 31);
+}
+__device__ __forceinline__ void hit_unkey(unsigned long long k, float& t, int& p) {
+    unsigned u = (unsigned)(k >> 32);
+    u = (u & 0x80000000u) ? (u ^ 0x80000000u) : ~u;
+    t = __uint_as_float(u);
+    if (t == 0.0f) t = __uint_as_float((unsigned)(k & 1ull) << 31);
+    p = (int)((k >> 1) & 0xFFFFu);
+}
+
+// GetClosestObject (Raytracer.cpp:123-140) over the LDS scene.  Must be called from
+// wave-uniform control flow; lanes with active == false take part in the cooperative phases
+// (they help test other lanes' rays) but trace nothing themselves.
+//
+// The reference scans ObjectsToRender in list order and keeps a hit only if its distance is
+// strictly smaller (:132), i.e. the result is the lexicographic minimum of (distance, list
+// index) over all valid hits.  We visit primitives in a different order, so an exact
+// distance tie is resolved by comparing list indices.
+//   1. uniform spheres: every lane, broadcast LDS reads, exact arithmetic.
+//   2. clustered spheres: each lane marks the clusters its ray can possibly touch
+//      (conservative bound, srt_scene_image.h); the wave then compacts all
+//      (ray, cluster) pairs into a work list with ballot/mbcnt prefix sums, lanes pull items,
+//      fetch the ray with __shfl, run the EXACT sphere arithmetic and merge through a 64-bit
+//      LDS atomicMin on hit_key — so the wave does sum(pairs)/64 rounds, not max-per-lane.
+//   3. boxes: every lane, exact arithmetic.
+__device__ __forceinline__ Hit closest_hit(const Lds& S, V3 o, V3 d, bool active) {
     float best = __builtin_inff();
     int bp = -1;
-    const int ns = S.ns, nb = S.nb;
-    // The sphere list is padded to a multiple of 4 with never-hit dummies (r*r = -1), so
-    // four broadcast ds_read_b128 are issued back to back and their latency overlaps the
-    // arithmetic of the previous spheres.
-    auto test = [&](const float4 s, int j) {
+    // exact sphere test of ray (ro, rd) against sphere s; updates (tb, pb) with the tie rule
+    auto test = [&](const float4 s, int p, V3 ro, V3 rd, bool on, float& tb, int& pb) {
         // Sphere::line_sphere_intersection (Object.hpp:104-141)
-        float Lx = s.x - o.x, Ly = s.y - o.y, Lz = s.z - o.z;                 // :115
-        float tc = fabsf((Lx * d.x + Ly * d.y) + Lz * d.z);                   // :118-119
-        float qx = d.x * tc + o.x, qy = d.y * tc + o.y, qz = d.z * tc + o.z;  // :121
-        float ex = qx - s.x, ey = qy - s.y, ez = qz - s.z;                    // :124
-        float d2 = (ex * ex + ey * ey) + ez * ez;                             // :125
-        bool cand = !(d2 > s.w);                                              // :127
-        if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {                      // wave-uniform skip
-            float t1 = tc - sqrtf(s.w - d2);                                  // :131-133
-            if (cand && t1 < best) {                                          // Raytracer.cpp:130-132
-                best = t1;
-                bp = j;
+        float Lx = s.x - ro.x, Ly = s.y - ro.y, Lz = s.z - ro.z;                    // :115
+        float tc = fabsf((Lx * rd.x + Ly * rd.y) + Lz * rd.z);                      // :118-119
+        float qx = rd.x * tc + ro.x, qy = rd.y * tc + ro.y, qz = rd.z * tc + ro.z;  // :121
+        float ex = qx - s.x, ey = qy - s.y, ez = qz - s.z;                          // :124
+        float d2 = (ex * ex + ey * ey) + ez * ez;                                   // :125
+        bool cand = on && !(d2 > s.w);                                              // :127
+        if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {                            // wave-uniform skip
+            float t1 = tc - sqrtf(s.w - d2);                                        // :131-133
+            if (cand) {
+                if (t1 < tb) {  // Raytracer.cpp:130-132
+                    tb = t1;
+                    pb = p;
+                } else if (t1 == tb && pb >= 0 && S.order(p) < S.order(pb)) {
+                    pb = p;  // same distance, earlier in ObjectsToRender
+                }
             }
         }
     };
-    const int ns4 = (ns + 3) & ~3;
-    for (int j = 0; j < ns4; j += 4) {
+    // ---- 1. uniform spheres: broadcast ds_read_b128, 4 per trip
+    for (int j = 0; j < S.nu4; j += 4) {
         const float4 s0 = S.v[j], s1 = S.v[j + 1], s2 = S.v[j + 2], s3 = S.v[j + 3];
-        test(s0, j);
-        test(s1, j + 1);
-        test(s2, j + 2);
-        test(s3, j + 3);
+        test(s0, j, o, d, active, best, bp);
+        test(s1, j + 1, o, d, active, best, bp);
+        test(s2, j + 2, o, d, active, best, bp);
+        test(s3, j + 3, o, d, active, best, bp);
     }
+    // ---- 2. clustered spheres
+    if (S.nc > 0) {
+        const float dd = __builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x));
+        const bool unit = fabsf(dd - 1.0f) <= 1e-6f;  // false for NaN
+        if (__builtin_amdgcn_ballot_w64(active && !unit) == 0ull) {
+            const float o1 = (fabsf(o.x) + fabsf(o.y)) + fabsf(o.z);
+            unsigned long long mask = 0ull;
+            for (int k = 0; k < S.nc; ++k) {  // phase 1: conservative cluster bounds, uniform reads
+                const float4 b = S.bound(k);
+                float Lx = b.x - o.x, Ly = b.y - o.y, Lz = b.z - o.z;
+                float LL = __builtin_fmaf(Lz, Lz, __builtin_fmaf(Ly, Ly, Lx * Lx));
+                float sd = __builtin_fmaf(Lz, d.z, __builtin_fmaf(Ly, d.y, Lx * d.x));
+                float Rinf = __builtin_fmaf(8e-6f, o1, b.w);
+                float lhs = __builtin_fmaf(-sd, sd, LL);
+                float rhs = __builtin_fmaf(4e-6f, LL, Rinf * Rinf);
+                if (lhs <= rhs) mask |= 1ull << k;
+            }
+            if (!active) mask = 0ull;
+            const int K4 = S.K >> 2;
+            // exclusive prefix sum of popcount(mask) over the wave, bit-sliced through ballots
+            const int cnt = __builtin_popcountll(mask);
+            int prefix = 0, total = 0;
+            for (int b = 0; b < 7; ++b) {
+                unsigned long long bal = __builtin_amdgcn_ballot_w64(((cnt >> b) & 1) != 0);
+                prefix += (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u)) << b;
+                total += __builtin_popcountll(bal) << b;
+            }
+            total = __builtin_amdgcn_readfirstlane(total);
+            if (total > 0 && total <= WORK_MAX) {
+                const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                // the lane's own best so far enters the merge slot
+                S.res[lane] = bp >= 0 ? hit_key(best, S.order(bp), bp) : ~0ull;
+                {  // scatter this lane's (lane, cluster) items behind its prefix
+                    unsigned long long m = mask;
+                    int w = prefix;
+                    while (__builtin_amdgcn_ballot_w64(m != 0ull) != 0ull) {
+                        if (m != 0ull) {
+                            S.work[w++] = (unsigned short)((lane << 8) | __builtin_ctzll(m));
+                            m &= m - 1ull;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int base = 0; base < total; base += 64) {  // rounds of 64 items
+                    const int w = base + lane;
+                    const bool on = w < total;
+                    const unsigned item = on ? S.work[w] : (unsigned)(lane << 8);
+                    const int src = (int)(item >> 8), k = (int)(item & 63u);
+                    V3 ro = v3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
+                    V3 rd = v3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
+                    float tb = __builtin_inff();
+                    int pb = -1;
+                    for (int i = 0; i < K4; ++i) {
+                        const int p = S.nu4 + (k * K4 + i) * 4;  // per-lane LDS gather
+                        const float4 s0 = S.v[p], s1 = S.v[p + 1], s2 = S.v[p + 2], s3 = S.v[p + 3];
+                        test(s0, p, ro, rd, on, tb, pb);
+                        test(s1, p + 1, ro, rd, on, tb, pb);
+                        test(s2, p + 2, ro, rd, on, tb, pb);
+                        test(s3, p + 3, ro, rd, on, tb, pb);
+                    }
+                    if (pb >= 0) atomicMin(&S.res[src], hit_key(tb, S.order(pb), pb));
+                }
+                __builtin_amdgcn_wave_barrier();
+                const unsigned long long r = S.res[lane];
+                if (r != ~0ull) hit_unkey(r, best, bp);
+            } else if (total > WORK_MAX) {  // pathological: per-lane loop over own candidates
+                while (__builtin_amdgcn_ballot_w64(mask != 0ull) != 0ull) {
+                    const bool on = mask != 0ull;
+                    const int k = on ? __builtin_ctzll(mask) : 0;
+                    mask &= mask - 1ull;
+                    for (int i = 0; i < K4; ++i) {
+                        const int p = S.nu4 + (k * K4 + i) * 4;
+                        const float4 s0 = S.v[p], s1 = S.v[p + 1], s2 = S.v[p + 2], s3 = S.v[p + 3];
+                        test(s0, p, o, d, on, best, bp);
+                        test(s1, p + 1, o, d, on, best, bp);
+                        test(s2, p + 2, o, d, on, best, bp);
+                        test(s3, p + 3, o, d, on, best, bp);
+                    }
+                }
+            }
+        } else {  // some lane's direction is not unit length (degenerate lerp): brute force
+            for (int j = S.nu4; j < S.nsT; j += 4) {
+                const float4 s0 = S.v[j], s1 = S.v[j + 1], s2 = S.v[j + 2], s3 = S.v[j + 3];
+                test(s0, j, o, d, active, best, bp);
+                test(s1, j + 1, o, d, active, best, bp);
+                test(s2, j + 2, o, d, active, best, bp);
+                test(s3, j + 3, o, d, active, best, bp);
+            }
+        }
+    }
+    // ---- 3. boxes
     Hit h;
     V3 bt1 = v3(0, 0, 0);
     BoxRay br;
+    const int nsT = S.nsT, nb = S.nb;
     if (nb > 0) {
         br = box_ray_setup(d);
-        int border = 0x7fffffff;
-        if (bp >= 0) border = __float_as_int(S.mat(bp, 2).w);
         for (int j = 0; j < nb; ++j) {
             const float4 c = S.box_c(j), hs = S.box_h(j);
             V3 t1;
             float dist = ibox_dist(br, v3(o.x - c.x, o.y - c.y, o.z - c.z), v3(hs.x, hs.y, hs.z), t1);
-            bool valid = dist != 3.402823466e+38f;  // Object.hpp:231
+            bool valid = active && dist != 3.402823466e+38f;  // Object.hpp:231
             if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
-                int ord = __float_as_int(S.mat(ns + j, 2).w);
-                if (valid && (dist < best || (dist == best && ord < border))) {
+                if (valid && (dist < best || (dist == best && bp >= 0 && S.order(nsT + j) < S.order(bp)))) {
                     best = dist;
-                    bp = ns + j;
-                    border = ord;
+                    bp = nsT + j;
                     bt1 = t1;
                 }
             }
@@ -199,7 +321,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, V3 o, V3 d) {
     h.t = best;
     h.prim = bp;
     h.p = v3(o.x + d.x * best, o.y + d.y * best, o.z + d.z * best);  // Object.hpp:136 / :229
-    if (bp >= ns) {
+    if (bp >= nsT) {
         h.n = ibox_normal(br, bt1);
     } else if (bp >= 0) {
         const float4 s = S.sphere(bp);
@@ -227,14 +349,17 @@ __device__ __forceinline__ RGB environment(const KernelParams& P, V3 d) {
     float sd = (d.x * (P.sun_dir[0] * -1) + d.y * (P.sun_dir[1] * -1)) + d.z * (P.sun_dir[2] * -1);
     bool sunny = (double)sd > 0.99;  // :79 float vs double literal
     RGB Sun{sunny ? clamp0(P.sun[0]) : 0.0f, sunny ? clamp0(P.sun[1]) : 0.0f, sunny ? clamp0(P.sun[2]) : 0.0f};
+    // one srt_powf call site for both branches (:81 powf(upd, 0.1f) / :87 powf(|upd|, .05f)):
+    // the arguments are selected per lane, so up- and down-going lanes do not serialize.
+    const bool up = upd > 0;
+    const float pw = srt_powf(up ? upd : fabsf(upd), up ? 0.1f : .05f);
     RGB t;
-    if (upd > 0) {
-        t = color_lerp(Horizon, Sky, srt_powf(upd, 0.1f));  // :81
+    if (up) {
+        t = color_lerp(Horizon, Sky, pw);  // :81
         RGB sky01{clamp0(Sky.r * 0.1f), clamp0(Sky.g * 0.1f), clamp0(Sky.b * 0.1f)};
-        t = color_lerp(t, sky01, upd);                      // :82
+        t = color_lerp(t, sky01, upd);     // :82
     } else {
-        upd = fabsf(upd);                                   // :86
-        t = color_lerp(Horizon, Ground, srt_powf(upd, .05f));  // :87
+        t = color_lerp(Horizon, Ground, pw);  // :86-87
     }
     return RGB{clamp0(t.r + Sun.r), clamp0(t.g + Sun.g), clamp0(t.b + Sun.b)};  // :83 / :87
 }
@@ -250,12 +375,15 @@ __device__ __forceinline__ uint32_t pack_channel(float v) {  // Common.hpp:190-2
     return (uint32_t)(uint8_t)s;
 }
 
-__global__ void __launch_bounds__(WG_THREADS) pathtrace_kernel(const KernelParams P) {
+template <int MIN_WAVES>
+__global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const KernelParams P) {
     extern __shared__ float4 lds_scene[];
     // ---- stage the scene image into LDS (coalesced 16-byte loads) -----------------
     for (int i = threadIdx.x; i < P.scene_vec4; i += WG_THREADS) lds_scene[i] = P.scene[i];
     __syncthreads();
-    Lds S{lds_scene, P.ns, P.nb};
+    char* scratch = reinterpret_cast<char*>(lds_scene + P.scene_vec4) + (threadIdx.x >> 6) * WAVE_SCRATCH_BYTES;
+    Lds S{lds_scene, P.nu4, P.nc, P.K, P.nsT, P.nb, P.off_bounds, P.off_box, P.off_mat,
+          reinterpret_cast<unsigned long long*>(scratch), reinterpret_cast<unsigned short*>(scratch + 64 * 8)};
 
     // ---- pixel of this lane ----------------------------------------------------------
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -275,7 +403,7 @@ __global__ void __launch_bounds__(WG_THREADS) pathtrace_kernel(const KernelParam
     const V3 cam = v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
 
     // ---- primary hit: identical for every sample ------------------------------------
-    const Hit h0 = closest_hit(S, cam, dir0);
+    const Hit h0 = closest_hit(S, cam, dir0, true);
 
     float4 acc = make_float4(0, 0, 0, 0);
     const size_t acc_idx = (size_t)pixel;
@@ -352,6 +480,7 @@ __global__ void __launch_bounds__(WG_THREADS) pathtrace_kernel(const KernelParam
 
     // ---- bounce loop with per-lane path regeneration ----------------------------------
     while (__builtin_amdgcn_ballot_w64(!done) != 0ull) {
+        V3 o = v3(0, 0, 0);
         if (!done) {
             if (bounce != 0) {  // :169-171
                 T = RGB{clamp0(T.r * 0.8f), clamp0(T.g * 0.8f), clamp0(T.b * 0.8f)};
@@ -373,8 +502,11 @@ __global__ void __launch_bounds__(WG_THREADS) pathtrace_kernel(const KernelParam
             V3 l = v3(sr.x * (1 - tt) + refl.x * tt, sr.y * (1 - tt) + refl.y * tt, sr.z * (1 - tt) + refl.z * tt);
             sray = normalized(l);  // :176
             const float ofs = .00001f;
-            V3 o = v3(hp.x + hn.x * ofs, hp.y + hn.y * ofs, hp.z + hn.z * ofs);  // :177
-            Hit h = closest_hit(S, o, sray);
+            o = v3(hp.x + hn.x * ofs, hp.y + hn.y * ofs, hp.z + hn.z * ofs);  // :177
+        }
+        // the scan runs in wave-uniform control flow: finished lanes help with other lanes' rays
+        const Hit h = closest_hit(S, o, sray, !done);
+        if (!done) {
             ++rays;
             bool end_path;
             if (h.prim < 0) {  // :178-181

@@ -1,0 +1,197 @@
+// srt_scene_image.h — host-side builder of the device scene image (flattened, LDS-shaped).
+//
+// ObjectsToRender (Raytracer.cpp:61) arrives as srt_object[] in list order.  The image is an
+// array of float4 that the kernel copies verbatim into LDS:
+//
+//   [0, nu4)                 "uniform" spheres (cx,cy,cz,r*r), list order, padded to a
+//                            multiple of 4 with never-hit dummies (0,0,0,-1).  Every lane
+//                            tests all of them (wave-uniform broadcast reads).
+//   [nu4, nsT)               clustered spheres: nc clusters of K (multiple of 4) spheres,
+//                            spatially grouped, padded with dummies.  nsT = nu4 + nc*K.
+//   [nsT, nsT+nc)            cluster bounds (Cx,Cy,Cz,Rg): a bounding sphere of the members,
+//                            inflated so that the kernel's cheap test is CONSERVATIVE with
+//                            respect to the reference's float arithmetic (proof below).
+//   [.., +2nb)               boxes (cx,cy,cz,_)(hx,hy,hz,_), list order.
+//   [off_mat, +3(nsT+nb))    three material rows per primitive id p (spheres: p = index in
+//                            [0,nsT); boxes: p = nsT + j):
+//                              (smoothness, specular_amount, base.r, base.g)
+//                              (base.b, emissive.r, emissive.g, emissive.b)
+//                              (specular.r, specular.g, specular.b, bits(list index))
+//
+// The list index restores the reference's tie rule (strict '<' in list order keeps the
+// lower index, Raytracer.cpp:132) after the spheres have been permuted.
+//
+// ---- why the cluster test is conservative -------------------------------------------------
+// Reference test for sphere j (Object.hpp:115-133), evaluated in binary32 without FMA:
+//   L = c-o; tc = |L.d|; e = (d*tc + o) - c; d2 = e.e; candidate iff !(d2 > r*r);
+//   recorded only if additionally t1 = tc - sqrt(r*r - d2) < best (so NaN never records).
+// Let D be the exact distance from c to the LINE through o along d, eps = 2^-24, and assume
+// finite inputs with |d.d - 1| <= 1e-6 (the kernel checks this and otherwise falls back to
+// the brute-force scan).  Bounding every rounding step:
+//   d2_float >= D^2 - [ 4.2e-7*D*(|L|+|o|) + 4e-7*D^2 + 2e-12*|L|^2 ]
+// (the |o| term appears because q = d*tc + o is rounded at the magnitude of absolute
+// coordinates).  For a sphere BEHIND the ray (L.d < 0) the mirrored point gives
+// |e|^2 = |L|^2 + (3+eta) s^2 >= |L|^2 >= D^2, so the same bound holds.  Hence a sphere can be
+// a candidate only if  D <= r + rho,  rho = 4e-6*(|o|+|c|+|L|) + 1e-5*r   (2x margin).
+// For a cluster with centre C and R_geo >= |c_j - C| + r_j for all members:
+//   D_C <= D_j + |c_j - C| <= R_geo*(1+1e-5) + 8e-6*(|o|_1 + cmax),   cmax = max |c_j|.
+// The kernel evaluates  lhs = fma(-s,s,LL)  (LL = |C-o|^2, s = (C-o).d, FMA chains) whose error
+// against D_C^2 is below 1.6e-6*LL, and passes the cluster iff
+//   lhs <= (Rg + 8e-6*|o|_1)^2 + 4e-6*LL,   Rg = R_geo*(1+1e-5) + 8e-6*cmax  rounded UP.
+// So "cluster fails" implies no member can be a candidate: culling never changes the result.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "srt_pathtrace.h"
+
+namespace srt {
+
+struct SceneLayout {
+    int nu4 = 0;      // uniform sphere slots (multiple of 4)
+    int nc = 0;       // clusters (<= 64)
+    int K = 4;        // sphere slots per cluster (multiple of 4)
+    int nsT = 0;      // nu4 + nc*K
+    int nb = 0;       // boxes
+    int off_bounds = 0, off_box = 0, off_mat = 0;
+    int total_vec4 = 0;
+    int n_spheres = 0;  // real spheres (for statistics)
+};
+
+inline uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) {  // 10 bits per axis
+    auto spread = [](uint32_t v) {
+        v &= 0x3ff;
+        v = (v | (v << 16)) & 0x030000FF;
+        v = (v | (v << 8)) & 0x0300F00F;
+        v = (v | (v << 4)) & 0x030C30C3;
+        v = (v | (v << 2)) & 0x09249249;
+        return v;
+    };
+    return spread(x) | (spread(y) << 1) | (spread(z) << 2);
+}
+
+// Builds the image. `cluster` = false puts every sphere in the uniform block.
+inline SceneLayout build_scene_image(const srt_object* objects, size_t count, bool cluster, std::vector<float4>& img) {
+    std::vector<int> spheres, boxes;
+    for (size_t i = 0; i < count; ++i) {
+        if (objects[i].type == SRT_OBJ_SPHERE) spheres.push_back((int)i);
+        if (objects[i].type == SRT_OBJ_BOX) boxes.push_back((int)i);
+    }
+    auto finite_sphere = [&](int i) {
+        const srt_object& o = objects[i];
+        return std::isfinite(o.position[0]) && std::isfinite(o.position[1]) && std::isfinite(o.position[2]) && std::isfinite(o.radius) &&
+               fabs((double)o.position[0]) < 1e15 && fabs((double)o.position[1]) < 1e15 && fabs((double)o.position[2]) < 1e15 &&
+               fabs((double)o.radius) < 1e15;
+    };
+    std::vector<int> uni, small;
+    if (cluster && spheres.size() >= 16) {
+        std::vector<double> radii;
+        for (int i : spheres)
+            if (finite_sphere(i)) radii.push_back(fabs((double)objects[i].radius));
+        double median = 0;
+        if (!radii.empty()) {
+            std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
+            median = radii[radii.size() / 2];
+        }
+        for (int i : spheres) {
+            bool big = !finite_sphere(i) || fabs((double)objects[i].radius) > 4.0 * median;
+            (big ? uni : small).push_back(i);
+        }
+        if (small.size() < 8) {  // not worth a second level
+            uni = spheres;
+            small.clear();
+        }
+    } else {
+        uni = spheres;
+    }
+
+    SceneLayout L;
+    L.n_spheres = (int)spheres.size();
+    L.nb = (int)boxes.size();
+    L.nu4 = ((int)uni.size() + 3) & ~3;
+    // order the small spheres along a Morton curve of their centres, then cut into clusters
+    if (!small.empty()) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (int i : small)
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = std::min(lo[a], (double)objects[i].position[a]);
+                hi[a] = std::max(hi[a], (double)objects[i].position[a]);
+            }
+        std::vector<std::pair<uint32_t, int>> keyed;
+        for (int i : small) {
+            uint32_t q[3];
+            for (int a = 0; a < 3; ++a) {
+                double ext = hi[a] - lo[a];
+                double t = ext > 0 ? ((double)objects[i].position[a] - lo[a]) / ext : 0.0;
+                q[a] = (uint32_t)std::min(1023.0, std::max(0.0, t * 1023.0));
+            }
+            keyed.push_back({morton3(q[0], q[1], q[2]), i});
+        }
+        std::stable_sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        for (size_t k = 0; k < keyed.size(); ++k) small[k] = keyed[k].second;
+        int K = 4;
+        while ((int)((small.size() + K - 1) / K) > 64) K += 4;
+        L.K = K;
+        L.nc = (int)((small.size() + K - 1) / K);
+    }
+    L.nsT = L.nu4 + L.nc * L.K;
+    L.off_bounds = L.nsT;
+    L.off_box = L.off_bounds + L.nc;
+    L.off_mat = L.off_box + 2 * L.nb;
+    L.total_vec4 = L.off_mat + 3 * (L.nsT + L.nb);
+
+    img.assign((size_t)std::max(L.total_vec4, 1), make_float4(0, 0, 0, 0));
+    const float4 dummy = make_float4(0, 0, 0, -1.0f);  // d2 > r*r always: never a candidate
+    for (int p = 0; p < L.nsT; ++p) img[p] = dummy;
+
+    auto put_material = [&](int p, int list_index) {
+        const srt_material& m = objects[list_index].material;
+        float ord;
+        int32_t idx = list_index;
+        memcpy(&ord, &idx, 4);
+        img[L.off_mat + 3 * p + 0] = make_float4(m.smoothness, m.specular_amount, m.base_color[0], m.base_color[1]);
+        img[L.off_mat + 3 * p + 1] = make_float4(m.base_color[2], m.emissive_color[0], m.emissive_color[1], m.emissive_color[2]);
+        img[L.off_mat + 3 * p + 2] = make_float4(m.specular_color[0], m.specular_color[1], m.specular_color[2], ord);
+    };
+    auto put_sphere = [&](int p, int i) {
+        const srt_object& o = objects[i];
+        img[p] = make_float4(o.position[0], o.position[1], o.position[2], o.radius * o.radius);  // Object.hpp:122
+        put_material(p, i);
+    };
+    for (size_t k = 0; k < uni.size(); ++k) put_sphere((int)k, uni[k]);
+    for (int c = 0; c < L.nc; ++c) {
+        const size_t b = (size_t)c * L.K, e = std::min(small.size(), b + L.K);
+        double C[3] = {0, 0, 0};
+        for (size_t k = b; k < e; ++k)
+            for (int a = 0; a < 3; ++a) C[a] += (double)objects[small[k]].position[a];
+        float Cf[3];
+        for (int a = 0; a < 3; ++a) Cf[a] = (float)(C[a] / (double)(e - b));
+        double Rgeo = 0, cmax = 0;
+        for (size_t k = b; k < e; ++k) {
+            const srt_object& o = objects[small[k]];
+            double dx = (double)o.position[0] - Cf[0], dy = (double)o.position[1] - Cf[1], dz = (double)o.position[2] - Cf[2];
+            Rgeo = std::max(Rgeo, sqrt(dx * dx + dy * dy + dz * dz) + fabs((double)o.radius));
+            cmax = std::max(cmax, fabs((double)o.position[0]) + fabs((double)o.position[1]) + fabs((double)o.position[2]));
+            put_sphere(L.nu4 + (int)k, small[k]);
+        }
+        double Rg = Rgeo * (1.0 + 1e-5) + 8e-6 * cmax + 1e-30;
+        float Rgf = (float)Rg;
+        if ((double)Rgf < Rg) Rgf = nextafterf(Rgf, INFINITY);
+        img[L.off_bounds + c] = make_float4(Cf[0], Cf[1], Cf[2], Rgf);
+    }
+    for (size_t j = 0; j < boxes.size(); ++j) {
+        const srt_object& o = objects[boxes[j]];
+        img[L.off_box + 2 * j] = make_float4(o.position[0], o.position[1], o.position[2], 0.0f);
+        img[L.off_box + 2 * j + 1] = make_float4(o.half_size[0], o.half_size[1], o.half_size[2], 0.0f);
+        put_material(L.nsT + (int)j, boxes[j]);
+    }
+    return L;
+}
+
+}  // namespace srt

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of kernel tuning variants in ONE process (cdna guide §5.4 rule 24).
+usage: python tests/ab_bench.py [--variants 0,1] [--rounds 7] [--scene Scene1] [--spp 32]"""
+import argparse
+import ctypes as C
+import importlib
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument("--variants", default="0,1")
+ap.add_argument("--rounds", type=int, default=7)
+ap.add_argument("--scene", default="Scene1")
+ap.add_argument("--spp", type=int, default=32)
+ap.add_argument("--bounces", type=int, default=8)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+a = ap.parse_args()
+srt = importlib.import_module("software-raytracer_amd")
+L = srt.load_library()
+L.srt_debug_set_variant.argtypes = [C.c_void_p, C.c_int]
+sc = srt.host.Scene(os.path.join(ROOT, "software-raytracer_amd", "scenes", a.scene + ".json"))
+objs, n = sc.objects_copy()
+pt = srt.PathTracer(a.width, a.height)
+pt.set_scene(objs, n)
+pt.set_camera(srt.default_camera())
+variants = [int(v) for v in a.variants.split(",")]
+times = {v: [] for v in variants}
+hashes = {}
+import hashlib
+for r in range(a.rounds + 1):
+    for v in variants:
+        L.srt_debug_set_variant(pt._h, v)
+        pt.render(spp=a.spp, bounces=a.bounces, seed=0)
+        ms = pt.stats().kernel_ms
+        if r:  # round 0 = warm-up
+            times[v].append(ms)
+        else:
+            hashes[v] = hashlib.sha256(pt.framebuffer().tobytes()).hexdigest()[:12]
+for v in variants:
+    t = times[v]
+    print("variant %d: median %.3f ms  min %.3f  max %.3f  hash %s  -> %.3e samples/s" %
+          (v, statistics.median(t), min(t), max(t), hashes[v], a.width * a.height * a.spp / (statistics.median(t) * 1e-3)))
+assert len(set(hashes.values())) == 1, "variants disagree!"
