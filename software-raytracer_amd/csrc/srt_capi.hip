@@ -270,6 +270,8 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
         return fail(ctx, SRT_ERR_INVALID_ARG, "srt_render: bad row band [%d,%d) for height %d", p->row_begin, p->row_end, H);
     if (p->first_sample < 1 || p->sample_count < 1 || p->max_bounces < 0)
         return fail(ctx, SRT_ERR_INVALID_ARG, "srt_render: first_sample/sample_count must be >= 1 and max_bounces >= 0");
+    if (p->sample_count > (1u << 20))
+        return fail(ctx, SRT_ERR_INVALID_ARG, "srt_render: sample_count is limited to 2^20 per call (render in several calls)");
     if ((uint64_t)p->first_sample + p->sample_count > 0x7fffffffull)
         return fail(ctx, SRT_ERR_INVALID_ARG, "srt_render: sample index overflows int (ACCUMULATIONFRAMES is an int)");
     SRT_HIP(ctx, hipSetDevice(ctx->device));
@@ -334,8 +336,10 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     // variants are a development aid for in-process A/B timing; all are bit-identical
     if (use == 1)
         hipLaunchKernelGGL(srt::pathtrace_kernel<5>, grid, block, lds_bytes, ctx->stream, K);
+    else if (use == 3)
+        hipLaunchKernelGGL(srt::pathtrace_kernel<3>, grid, block, lds_bytes, ctx->stream, K);
     else
-        hipLaunchKernelGGL(srt::pathtrace_kernel<1>, grid, block, lds_bytes, ctx->stream, K);
+        hipLaunchKernelGGL(srt::pathtrace_kernel<4>, grid, block, lds_bytes, ctx->stream, K);
     SRT_HIP(ctx, hipGetLastError());
     SRT_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
     ctx->launched = true;

@@ -70,7 +70,9 @@ constexpr int WG_W = TILE_W * WG_TILES_X, WG_H = TILE_H * WG_TILES_Y;
 // per-wave LDS scratch behind the scene image: work list of (ray lane, cluster) items + one
 // 64-bit result slot per lane (balanced phase 2 of closest_hit)
 constexpr int WORK_MAX = 512;
-constexpr int WAVE_SCRATCH_BYTES = 64 * 8 + WORK_MAX * 2;
+constexpr int RING_DEPTH = 4;  // ring entries per slot when all 64 pixels of the tile are traced
+// per-wave: 64 result slots (8 B) | work list (2 B) | 64 pixel records (48 B) | ring (16 B)
+constexpr int WAVE_SCRATCH_BYTES = 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4 + 64 * RING_DEPTH * 16;
 constexpr int WG_SCRATCH_BYTES = WAVE_SCRATCH_BYTES * WG_TILES_X * WG_TILES_Y;
 
 __device__ __forceinline__ float clamp0(float v) { return v < 0 ? 0.0f : v; }  // Common.hpp:254-257
@@ -91,6 +93,8 @@ struct Lds {
     int nu4, nc, K, nsT, nb, off_bounds, off_box, off_mat;
     unsigned long long* res;  // this wave's 64 result slots
     unsigned short* work;     // this wave's work list
+    float* pix;               // this wave's 64 pixel records (12 floats each)
+    float4* ring;             // this wave's sample-colour ring
     __device__ __forceinline__ float4 sphere(int p) const { return v[p]; }
     __device__ __forceinline__ float4 bound(int k) const { return v[off_bounds + k]; }
     __device__ __forceinline__ float4 box_c(int j) const { return v[off_box + 2 * j]; }
@@ -383,7 +387,9 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     __syncthreads();
     char* scratch = reinterpret_cast<char*>(lds_scene + P.scene_vec4) + (threadIdx.x >> 6) * WAVE_SCRATCH_BYTES;
     Lds S{lds_scene, P.nu4, P.nc, P.K, P.nsT, P.nb, P.off_bounds, P.off_box, P.off_mat,
-          reinterpret_cast<unsigned long long*>(scratch), reinterpret_cast<unsigned short*>(scratch + 64 * 8)};
+          reinterpret_cast<unsigned long long*>(scratch), reinterpret_cast<unsigned short*>(scratch + 64 * 8),
+          reinterpret_cast<float*>(scratch + 64 * 8 + WORK_MAX * 2),
+          reinterpret_cast<float4*>(scratch + 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4)};
 
     // ---- pixel of this lane ----------------------------------------------------------
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -405,151 +411,220 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     // ---- primary hit: identical for every sample ------------------------------------
     const Hit h0 = closest_hit(S, cam, dir0, true);
 
-    float4 acc = make_float4(0, 0, 0, 0);
-    const size_t acc_idx = (size_t)pixel;
     const bool reset = (P.flags & 1u) != 0;
-    if (in_range && !reset) acc = P.accumulator[acc_idx];
-
     const uint32_t count = P.sample_count;
     const int B = P.max_bounces;
-    uint32_t s = 0;  // samples finished by this lane
     unsigned rays = 0;
 
-    // SetScreenPixel accumulate half (Raytracer.cpp:65-71); colour alpha is always +0
-    auto accumulate = [&](RGB c) {
-        const uint32_t frame = P.first_sample + s;
-        if (s == 0 && reset) {
+    // SetScreenPixel accumulate half (Raytracer.cpp:65-71) for sample index sidx (0-based in
+    // this launch); the colour's alpha is always +0
+    auto accumulate = [&](float4& acc, RGB c, uint32_t sidx) {
+        const uint32_t frame = P.first_sample + sidx;
+        if (sidx == 0 && reset) {
             acc = make_float4(c.r, c.g, c.b, 0.0f);
         } else {
-            float weight = (float)(1.0 / (double)(int)frame);  // :66
+            // :66  float weight = 1.0 / ACCUMULATIONFRAMES (double divide, rounded once).  For
+            // frame <= 2^24 the float divide gives the same bits (1/f cannot sit within 2^-53
+            // of a binary32 rounding boundary unless it is exact; checked exhaustively in tests).
+            float weight = frame <= 16777216u ? 1.0f / (float)(int)frame : (float)(1.0 / (double)(int)frame);
             float om = 1 - weight;
             acc.x = clamp0(clamp0(acc.x * om) + clamp0(c.r * weight));  // :67
             acc.y = clamp0(clamp0(acc.y * om) + clamp0(c.g * weight));
             acc.z = clamp0(clamp0(acc.z * om) + clamp0(c.b * weight));
             acc.w = clamp0(clamp0(acc.w * om) + clamp0(0.0f * weight));
         }
-        ++s;
     };
-
-    bool done = !in_range;
-    // path state
-    RGB L{0, 0, 0}, T{0, 0, 0};
-    V3 sray = dir0, hn = h0.n, hp = h0.p;
-    int hprim = h0.prim;
-    float spec = 0.0f;
-    int bounce = 0;
-    uint32_t rng = 0;
-
-    RGB E0{0, 0, 0}, Base0{0, 0, 0};
-    float specAmt0 = 0;
-    if (h0.prim >= 0) {
-        float4 m0 = S.mat(h0.prim, 0), m1 = S.mat(h0.prim, 1);
-        specAmt0 = m0.y;
-        Base0 = RGB{clamp0(m0.z), clamp0(m0.w), clamp0(m1.x)};
-        E0 = RGB{clamp0(m1.y), clamp0(m1.z), clamp0(m1.w)};
-    }
-
-    auto start_path = [&]() {  // Raytracer.cpp:162-166 for the next sample of this lane
-        rng = srt_rng_key(P.seed, pixel, P.first_sample + s);
-        uint32_t r = srt_mix32(rng) >> 17;
-        rng += 0x9E3779B9U;
-        spec = (specAmt0 >= ((float)r / (float)SRT_RAND_MAX)) ? 1.0f : 0.0f;  // :165
-        L = E0;                                                                 // :162
-        T = Base0;                                                              // :163
-        sray = dir0;                                                            // :164
-        hn = h0.n;
-        hp = h0.p;
-        hprim = h0.prim;
-        bounce = 0;
-    };
-
-    if (!done) {
-        if (h0.prim < 0) {  // primary miss: the sample colour is env(dir0) every frame (:143-145)
-            RGB c = environment(P, dir0);
-            for (uint32_t i = 0; i < count; ++i) accumulate(c);
-            rays += count;
-            done = true;
-        } else if (B <= 0) {  // no bounce loop: colour = EmissiveColor (:162,212)
-            for (uint32_t i = 0; i < count; ++i) accumulate(E0);
-            rays += count;
-            done = true;
-        } else {
-            start_path();
-        }
-    }
-
-    // ---- bounce loop with per-lane path regeneration ----------------------------------
-    while (__builtin_amdgcn_ballot_w64(!done) != 0ull) {
-        V3 o = v3(0, 0, 0);
-        if (!done) {
-            if (bounce != 0) {  // :169-171
-                T = RGB{clamp0(T.r * 0.8f), clamp0(T.g * 0.8f), clamp0(T.b * 0.8f)};
-            }
-            // reflectedRay = sray.Reflect(normal)  (:172, Common.hpp:163-165)
-            float k2 = 2 * dot3(sray, hn);
-            V3 refl = v3(sray.x - hn.x * k2, sray.y - hn.y * k2, sray.z - hn.z * k2);
-            // GetRandomNormalOrientedHemisphere (:90-105): exactly three draws, x then y then z
-            uint32_t r0 = srt_mix32(rng) >> 17;
-            uint32_t r1 = srt_mix32(rng + 0x9E3779B9U) >> 17;
-            uint32_t r2 = srt_mix32(rng + 2u * 0x9E3779B9U) >> 17;
-            rng += 3u * 0x9E3779B9U;
-            V3 sr = v3(((float)r0 / (float)SRT_RAND_MAX - 0.5f) * 2, ((float)r1 / (float)SRT_RAND_MAX - 0.5f) * 2,
-                       ((float)r2 / (float)SRT_RAND_MAX - 0.5f) * 2);
-            sr = normalized(sr);
-            if (dot3(sr, hn) < 0) sr = v3(sr.x * -1, sr.y * -1, sr.z * -1);
-            // float3::Lerp(sray, reflectedRay, Smoothness * specularProb)  (:175)
-            float tt = S.mat(hprim, 0).x * spec;
-            V3 l = v3(sr.x * (1 - tt) + refl.x * tt, sr.y * (1 - tt) + refl.y * tt, sr.z * (1 - tt) + refl.z * tt);
-            sray = normalized(l);  // :176
-            const float ofs = .00001f;
-            o = v3(hp.x + hn.x * ofs, hp.y + hn.y * ofs, hp.z + hn.z * ofs);  // :177
-        }
-        // the scan runs in wave-uniform control flow: finished lanes help with other lanes' rays
-        const Hit h = closest_hit(S, o, sray, !done);
-        if (!done) {
-            ++rays;
-            bool end_path;
-            if (h.prim < 0) {  // :178-181
-                RGB e = environment(P, sray);
-                L = RGB{clamp0(L.r + clamp0(e.r * T.r)), clamp0(L.g + clamp0(e.g * T.g)), clamp0(L.b + clamp0(e.b * T.b))};
-                end_path = true;
-            } else {
-                float4 m0 = S.mat(h.prim, 0), m1 = S.mat(h.prim, 1), m2 = S.mat(h.prim, 2);
-                uint32_t r = srt_mix32(rng) >> 17;
-                rng += 0x9E3779B9U;
-                spec = (m0.y >= ((float)r / (float)SRT_RAND_MAX)) ? 1.0f : 0.0f;  // :182
-                RGB Em{clamp0(m1.y), clamp0(m1.z), clamp0(m1.w)};
-                L = RGB{clamp0(L.r + clamp0(Em.r * T.r)), clamp0(L.g + clamp0(Em.g * T.g)), clamp0(L.b + clamp0(Em.b * T.b))};  // :183
-                RGB Bc{clamp0(m0.z), clamp0(m0.w), clamp0(m1.x)}, Sc{clamp0(m2.x), clamp0(m2.y), clamp0(m2.z)};
-                RGB f = color_lerp(Bc, Sc, spec);                                   // :184
-                T = RGB{clamp0(T.r * f.r), clamp0(T.g * f.g), clamp0(T.b * f.b)};
-                hn = h.n;
-                hp = h.p;
-                hprim = h.prim;
-                ++bounce;
-                end_path = bounce >= B;
-            }
-            if (end_path) {
-                ++rays;  // the sample's primary GetClosestObject call (:142)
-                accumulate(L);
-                if (s >= count)
-                    done = true;
-                else
-                    start_path();
-            }
-        }
-    }
-
-    // ---- SetScreenPixel tone-map + pack (Raytracer.cpp:73-75) -------------------------
-    if (in_range) {
-        P.accumulator[acc_idx] = acc;
+    // SetScreenPixel tone-map + pack + the two stores (Raytracer.cpp:64,73-75)
+    auto write_pixel = [&](uint32_t pix, const float4 acc) {
+        P.accumulator[pix] = acc;
         float r = clamp0(acc.x / clamp0(1.0f + acc.x));
         float g = clamp0(acc.y / clamp0(1.0f + acc.y));
         float b = clamp0(acc.z / clamp0(1.0f + acc.z));
         float a = clamp0(acc.w / clamp0(0.0f + acc.w));
         uint32_t px = pack_channel(a) << 24 | pack_channel(r) << 16 | pack_channel(g) << 8 | pack_channel(b);
-        P.framebuffer[(size_t)(H - 1 - y) * W + x] = px;  // :64
+        const uint32_t py = pix / (uint32_t)W, pxx = pix - py * (uint32_t)W;
+        P.framebuffer[(size_t)(H - 1 - (int)py) * W + pxx] = px;
+    };
+
+    // ---- pixels whose colour does not depend on the sample: finish them right here --------
+    //  primary miss -> env(dir0) every frame (:143-145); MAXBOUNCES == 0 -> EmissiveColor (:162,212)
+    const bool traced = in_range && h0.prim >= 0 && B > 0;
+    if (in_range && !traced) {
+        RGB c;
+        if (h0.prim < 0) {
+            c = environment(P, dir0);
+        } else {
+            float4 m1 = S.mat(h0.prim, 1);
+            c = RGB{clamp0(m1.y), clamp0(m1.z), clamp0(m1.w)};
+        }
+        float4 acc = reset ? make_float4(0, 0, 0, 0) : P.accumulator[pixel];
+        for (uint32_t i = 0; i < count; ++i) accumulate(acc, c, i);
+        rays += count;
+        write_pixel(pixel, acc);
     }
+
+    // ---- wave-level path pool -----------------------------------------------------------------
+    // The pixels that need tracing are compacted into slots 0..n_hit-1 (ballot + mbcnt).  A task
+    // is (slot, sample); tasks are handed out in sample-major order to whichever lane is free,
+    // so every lane stays busy regardless of how hit pixels and path lengths are distributed
+    // over the tile.  A finished sample colour goes into a small LDS ring; lane k owns slot k
+    // and folds the ring into the running mean strictly in sample order (the mean is
+    // order-dependent, Raytracer.cpp:67), then stores the pixel at the end.
+    const unsigned long long hitmask = __builtin_amdgcn_ballot_w64(traced);
+    const int n_hit = __builtin_popcountll(hitmask);
+    if (n_hit > 0) {
+        float* rec = S.pix;  // [64][12]: dir0, n0, p0, prim0, pixel
+        if (traced) {
+            const int slot = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hitmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hitmask, 0u));
+            float* r = rec + slot * 12;
+            r[0] = dir0.x, r[1] = dir0.y, r[2] = dir0.z;
+            r[3] = h0.n.x, r[4] = h0.n.y, r[5] = h0.n.z;
+            r[6] = h0.p.x, r[7] = h0.p.y, r[8] = h0.p.z;
+            r[9] = __int_as_float(h0.prim);
+            r[10] = __uint_as_float(pixel);
+        }
+        const int depth = (64 * RING_DEPTH) / n_hit;  // ring entries per slot (>= RING_DEPTH)
+        float4* ring = S.ring;                        // [depth][n_hit] of (r, g, b, tag)
+        for (int i = lane; i < 64 * RING_DEPTH; i += 64) ring[i] = make_float4(0, 0, 0, __uint_as_float(0xFFFFFFFFu));
+        __builtin_amdgcn_wave_barrier();
+
+        // owner state (lane k owns slot k)
+        const bool owner = lane < n_hit;
+        uint32_t own_pixel = 0, own_done = owner ? 0u : count;  // samples folded so far
+        float4 acc = make_float4(0, 0, 0, 0);
+        if (owner) {
+            own_pixel = __float_as_uint(rec[lane * 12 + 10]);
+            if (!reset) acc = P.accumulator[own_pixel];
+        }
+
+        // path state of the task this lane is running
+        bool busy = false;
+        int slot = 0;
+        uint32_t sidx = 0;
+        RGB L{0, 0, 0}, T{0, 0, 0};
+        V3 sray = v3(0, 0, 1), hn = v3(0, 0, 0), hp = v3(0, 0, 0);
+        int hprim = 0, bounce = 0;
+        float spec = 0.0f;
+        uint32_t rng = 0;
+
+        const uint32_t total = (uint32_t)n_hit * count;
+        uint32_t next = 0;  // wave-uniform: next task to hand out
+
+        while (true) {
+            // ---- fold finished samples, in order, into the owners' running means
+            for (int it = 0; it < depth; ++it) {
+                bool ready = false;
+                float4 e = make_float4(0, 0, 0, 0);
+                if (own_done < count) {
+                    e = ring[(own_done % (uint32_t)depth) * n_hit + lane];
+                    ready = __float_as_uint(e.w) == own_done;
+                }
+                if (__builtin_amdgcn_ballot_w64(ready) == 0ull) break;
+                if (ready) {
+                    accumulate(acc, RGB{e.x, e.y, e.z}, own_done);
+                    ++own_done;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(own_done < count) == 0ull) break;  // every slot finished
+
+            // ---- hand out tasks: at most `depth` samples ahead of the slowest slot
+            uint32_t fmin = own_done;
+            for (int off = 32; off > 0; off >>= 1) {
+                uint32_t o2 = (uint32_t)__shfl_xor((int)fmin, off);
+                fmin = o2 < fmin ? o2 : fmin;
+            }
+            unsigned long long lim64 = ((unsigned long long)fmin + (unsigned)depth) * (unsigned)n_hit;
+            const uint32_t limit = lim64 < total ? (uint32_t)lim64 : total;
+            const unsigned long long want = __builtin_amdgcn_ballot_w64(!busy);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
+            const uint32_t t = next + rank;
+            if (!busy && t < limit) {
+                sidx = t / (uint32_t)n_hit;
+                slot = (int)(t - sidx * (uint32_t)n_hit);
+                const float* r = rec + slot * 12;
+                const int prim0 = __float_as_int(r[9]);
+                // Raytracer.cpp:162-166 for sample sidx of that pixel
+                rng = srt_rng_key(P.seed, __float_as_uint(r[10]), P.first_sample + sidx);
+                uint32_t rr = srt_mix32(rng) >> 17;
+                rng += 0x9E3779B9U;
+                float4 m0 = S.mat(prim0, 0), m1 = S.mat(prim0, 1);
+                spec = (m0.y >= ((float)rr / (float)SRT_RAND_MAX)) ? 1.0f : 0.0f;  // :165
+                L = RGB{clamp0(m1.y), clamp0(m1.z), clamp0(m1.w)};                 // :162
+                T = RGB{clamp0(m0.z), clamp0(m0.w), clamp0(m1.x)};                 // :163
+                sray = v3(r[0], r[1], r[2]);                                       // :164
+                hn = v3(r[3], r[4], r[5]);
+                hp = v3(r[6], r[7], r[8]);
+                hprim = prim0;
+                bounce = 0;
+                busy = true;
+                ++rays;  // the sample's primary GetClosestObject call (:142)
+            }
+            {
+                const uint32_t avail = limit > next ? limit - next : 0u;
+                const uint32_t wanted = (uint32_t)__builtin_popcountll(want);
+                next += wanted < avail ? wanted : avail;
+            }
+
+            // ---- one bounce for every busy lane
+            V3 o = v3(0, 0, 0);
+            if (busy) {
+                if (bounce != 0) {  // :169-171
+                    T = RGB{clamp0(T.r * 0.8f), clamp0(T.g * 0.8f), clamp0(T.b * 0.8f)};
+                }
+                // reflectedRay = sray.Reflect(normal)  (:172, Common.hpp:163-165)
+                float k2 = 2 * dot3(sray, hn);
+                V3 refl = v3(sray.x - hn.x * k2, sray.y - hn.y * k2, sray.z - hn.z * k2);
+                // GetRandomNormalOrientedHemisphere (:90-105): exactly three draws, x then y then z
+                uint32_t r0 = srt_mix32(rng) >> 17;
+                uint32_t r1 = srt_mix32(rng + 0x9E3779B9U) >> 17;
+                uint32_t r2 = srt_mix32(rng + 2u * 0x9E3779B9U) >> 17;
+                rng += 3u * 0x9E3779B9U;
+                V3 sr = v3(((float)r0 / (float)SRT_RAND_MAX - 0.5f) * 2, ((float)r1 / (float)SRT_RAND_MAX - 0.5f) * 2,
+                           ((float)r2 / (float)SRT_RAND_MAX - 0.5f) * 2);
+                sr = normalized(sr);
+                if (dot3(sr, hn) < 0) sr = v3(sr.x * -1, sr.y * -1, sr.z * -1);
+                // float3::Lerp(sray, reflectedRay, Smoothness * specularProb)  (:175)
+                float tt = S.mat(hprim, 0).x * spec;
+                V3 l = v3(sr.x * (1 - tt) + refl.x * tt, sr.y * (1 - tt) + refl.y * tt, sr.z * (1 - tt) + refl.z * tt);
+                sray = normalized(l);  // :176
+                const float ofs = .00001f;
+                o = v3(hp.x + hn.x * ofs, hp.y + hn.y * ofs, hp.z + hn.z * ofs);  // :177
+            }
+            // the scan runs in wave-uniform control flow: idle lanes help with other lanes' rays
+            const Hit h = closest_hit(S, o, sray, busy);
+            if (busy) {
+                ++rays;
+                bool end_path;
+                if (h.prim < 0) {  // :178-181
+                    RGB e = environment(P, sray);
+                    L = RGB{clamp0(L.r + clamp0(e.r * T.r)), clamp0(L.g + clamp0(e.g * T.g)), clamp0(L.b + clamp0(e.b * T.b))};
+                    end_path = true;
+                } else {
+                    float4 m0 = S.mat(h.prim, 0), m1 = S.mat(h.prim, 1), m2 = S.mat(h.prim, 2);
+                    uint32_t r = srt_mix32(rng) >> 17;
+                    rng += 0x9E3779B9U;
+                    spec = (m0.y >= ((float)r / (float)SRT_RAND_MAX)) ? 1.0f : 0.0f;  // :182
+                    RGB Em{clamp0(m1.y), clamp0(m1.z), clamp0(m1.w)};
+                    L = RGB{clamp0(L.r + clamp0(Em.r * T.r)), clamp0(L.g + clamp0(Em.g * T.g)), clamp0(L.b + clamp0(Em.b * T.b))};  // :183
+                    RGB Bc{clamp0(m0.z), clamp0(m0.w), clamp0(m1.x)}, Sc{clamp0(m2.x), clamp0(m2.y), clamp0(m2.z)};
+                    RGB f = color_lerp(Bc, Sc, spec);                                   // :184
+                    T = RGB{clamp0(T.r * f.r), clamp0(T.g * f.g), clamp0(T.b * f.b)};
+                    hn = h.n;
+                    hp = h.p;
+                    hprim = h.prim;
+                    ++bounce;
+                    end_path = bounce >= B;
+                }
+                if (end_path) {  // hand the sample colour to the slot's owner
+                    ring[(sidx % (uint32_t)depth) * n_hit + slot] = make_float4(L.r, L.g, L.b, __uint_as_float(sidx));
+                    busy = false;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (owner) write_pixel(own_pixel, acc);
+    }
+
     if (P.flags & 2u) {  // SRT_RENDER_COUNT_RAYS
         unsigned long long tot = rays;
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
