@@ -507,8 +507,10 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         float spec = 0.0f;
         uint32_t rng = 0;
 
-        const uint32_t total = (uint32_t)n_hit * count;
-        uint32_t next = 0;  // wave-uniform: next task to hand out
+        // per-slot hand-out state, kept by the owner lane: samples [0, own_next) have been
+        // handed out, [0, own_done) folded.  A slot may run `depth` samples ahead of its own
+        // fold point (ring capacity); slots do not wait for each other.
+        uint32_t own_next = own_done;
 
         while (true) {
             // ---- fold finished samples, in order, into the owners' running means
@@ -527,42 +529,45 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             }
             if (__builtin_amdgcn_ballot_w64(own_done < count) == 0ull) break;  // every slot finished
 
-            // ---- hand out tasks: at most `depth` samples ahead of the slowest slot
-            uint32_t fmin = own_done;
-            for (int off = 32; off > 0; off >>= 1) {
-                uint32_t o2 = (uint32_t)__shfl_xor((int)fmin, off);
-                fmin = o2 < fmin ? o2 : fmin;
-            }
-            unsigned long long lim64 = ((unsigned long long)fmin + (unsigned)depth) * (unsigned)n_hit;
-            const uint32_t limit = lim64 < total ? (uint32_t)lim64 : total;
-            const unsigned long long want = __builtin_amdgcn_ballot_w64(!busy);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
-            const uint32_t t = next + rank;
-            if (!busy && t < limit) {
-                sidx = t / (uint32_t)n_hit;
-                slot = (int)(t - sidx * (uint32_t)n_hit);
-                const float* r = rec + slot * 12;
-                const int prim0 = __float_as_int(r[9]);
-                // Raytracer.cpp:162-166 for sample sidx of that pixel
-                rng = srt_rng_key(P.seed, __float_as_uint(r[10]), P.first_sample + sidx);
-                uint32_t rr = srt_mix32(rng) >> 17;
-                rng += 0x9E3779B9U;
-                float4 m0 = S.mat(prim0, 0), m1 = S.mat(prim0, 1);
-                spec = (m0.y >= ((float)rr / (float)SRT_RAND_MAX)) ? 1.0f : 0.0f;  // :165
-                L = RGB{clamp0(m1.y), clamp0(m1.z), clamp0(m1.w)};                 // :162
-                T = RGB{clamp0(m0.z), clamp0(m0.w), clamp0(m1.x)};                 // :163
-                sray = v3(r[0], r[1], r[2]);                                       // :164
-                hn = v3(r[3], r[4], r[5]);
-                hp = v3(r[6], r[7], r[8]);
-                hprim = prim0;
-                bounce = 0;
-                busy = true;
-                ++rays;  // the sample's primary GetClosestObject call (:142)
-            }
-            {
-                const uint32_t avail = limit > next ? limit - next : 0u;
-                const uint32_t wanted = (uint32_t)__builtin_popcountll(want);
-                next += wanted < avail ? wanted : avail;
+            // ---- hand out tasks: the i-th free lane takes the next sample of the i-th slot
+            // that has ring capacity (ballot ranks on both sides, matched through S.work)
+            for (int pass = 0; pass < 2; ++pass) {
+                const unsigned long long freem = __builtin_amdgcn_ballot_w64(!busy);
+                const bool can = own_next < count && own_next < own_done + (uint32_t)depth;
+                const unsigned long long canm = __builtin_amdgcn_ballot_w64(can);
+                if (freem == 0ull || canm == 0ull) break;
+                const int nfree = __builtin_popcountll(freem);
+                const int crank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(canm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)canm, 0u));
+                const int frank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(freem >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)freem, 0u));
+                unsigned* match = reinterpret_cast<unsigned*>(S.work);  // [64] of (sample << 6 | slot)
+                if (can && crank < nfree) {
+                    match[crank] = (own_next << 6) | (unsigned)lane;
+                    ++own_next;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (!busy && frank < __builtin_popcountll(canm)) {
+                    const unsigned m = match[frank];
+                    sidx = m >> 6;
+                    slot = (int)(m & 63u);
+                    const float* r = rec + slot * 12;
+                    const int prim0 = __float_as_int(r[9]);
+                    // Raytracer.cpp:162-166 for sample sidx of that pixel
+                    rng = srt_rng_key(P.seed, __float_as_uint(r[10]), P.first_sample + sidx);
+                    uint32_t rr = srt_mix32(rng) >> 17;
+                    rng += 0x9E3779B9U;
+                    float4 m0 = S.mat(prim0, 0), m1 = S.mat(prim0, 1);
+                    spec = (m0.y >= ((float)rr / (float)SRT_RAND_MAX)) ? 1.0f : 0.0f;  // :165
+                    L = RGB{clamp0(m1.y), clamp0(m1.z), clamp0(m1.w)};                 // :162
+                    T = RGB{clamp0(m0.z), clamp0(m0.w), clamp0(m1.x)};                 // :163
+                    sray = v3(r[0], r[1], r[2]);                                       // :164
+                    hn = v3(r[3], r[4], r[5]);
+                    hp = v3(r[6], r[7], r[8]);
+                    hprim = prim0;
+                    bounce = 0;
+                    busy = true;
+                    ++rays;  // the sample's primary GetClosestObject call (:142)
+                }
+                __builtin_amdgcn_wave_barrier();
             }
 
             // ---- one bounce for every busy lane
