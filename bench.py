@@ -87,11 +87,20 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product path has no CPU fallback")
+    # SRT_BENCH_REHEARSAL=1: every rank shares cuda:0 and the collectives run over gloo with
+    # host staging — only to exercise the multi-rank control flow on a one-GPU box.
+    rehearsal = os.environ.get("SRT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    cdev = torch.device("cpu") if rehearsal else dev  # where small collective payloads live
 
     srt = importlib.import_module("software-raytracer_amd")
     stripes = importlib.import_module("software-raytracer_amd.stripes")
@@ -136,9 +145,16 @@ def main():
         bands = stripes.partition_rows(H, world)
     rb, re = bands[rank]
 
+    host_frame = torch.zeros((H, W), dtype=torch.int32) if rehearsal else None
+
     def step(count_rays=False):
         pt.render(spp=spp, bounces=args.bounces, seed=SEED, first_sample=1, reset=True, rows=(rb, re), count_rays=count_rays)
-        stripes.gather_bands(frame, bands, rank, world, dist)
+        if rehearsal and world > 1:  # gloo cannot move device memory: stage through the host
+            stream.synchronize()
+            host_frame[rb:re].copy_(frame[rb:re])
+            stripes.gather_bands(host_frame, bands, rank, world, dist)
+        else:
+            stripes.gather_bands(frame, bands, rank, world, dist)
 
     def fence():
         if world > 1:
@@ -155,7 +171,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -175,12 +191,28 @@ def main():
     value = total_samples * args.steps / dt
 
     if world > 1:
-        info = torch.tensor([k_ms, float(rays), float(local_samples)], dtype=torch.float64, device=dev)
+        info = torch.tensor([k_ms, float(rays), float(local_samples)], dtype=torch.float64, device=cdev)
         allinfo = [torch.zeros_like(info) for _ in range(world)]
         dist.all_gather(allinfo, info)
         per_rank = [[float(x) for x in t.tolist()] for t in allinfo]
     else:
         per_rank = [[k_ms, float(rays), float(local_samples)]]
+
+    # the gathered multi-rank frame must equal a single-device render of the whole frame
+    stripe_parity = None
+    if world > 1:
+        step()
+        fence()
+        if rank == 0:
+            import numpy as np
+
+            gathered = (host_frame if rehearsal else frame.cpu()).numpy().view(np.uint32)
+            chk = srt.PathTracer(W, H, device=local_rank)
+            chk.set_scene(objs, n_obj)
+            chk.set_camera(srt.default_camera(FOV))
+            chk.render(spp=spp, bounces=args.bounces, seed=SEED)
+            stripe_parity = bool(np.array_equal(chk.framebuffer(), gathered))
+            chk.close()
 
     out = None
     if rank == 0:
@@ -242,6 +274,13 @@ def main():
             },
             "per_rank": [{"kernel_ms": p[0], "rays_per_sample": p[1] / p[2], "rows": list(bands[i])} for i, p in enumerate(per_rank)],
         }
+        if world > 1:
+            out["stripe_parity_vs_single_device"] = stripe_parity
+            if stripe_parity is False:
+                out["value"] = None
+                out["error"] = "gathered row stripes differ from the single-device frame; speed not reported"
+        if rehearsal:
+            out["rehearsal"] = "all ranks on cuda:0, gloo + host staging: control-flow test only, not a measurement"
 
     # ---- CPU baseline + in-run parity (rank 0, N = 1 only) -----------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
