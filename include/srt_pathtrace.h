@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SRT_ABI_VERSION 1
+#define SRT_ABI_VERSION 2
 
 typedef enum srt_status {
     SRT_OK = 0,
@@ -101,6 +101,8 @@ typedef struct srt_camera {
 
 #define SRT_RENDER_RESET 1u       /* first sample of this call overwrites (setFrame, :69-71) */
 #define SRT_RENDER_COUNT_RAYS 2u  /* fill srt_stats.rays (costs one atomic per wave)       */
+#define SRT_RENDER_PREVIEW 4u     /* SIMPLEDRAW == true: the one-ray preview shader (:147-160)
+                                     instead of the path-traced branch (:162-185)           */
 
 /* One render call = sample_count successive "frames" of the reference's loop over a
  * band of memory rows, all on the device, accumulator kept in registers in between.
@@ -116,6 +118,13 @@ typedef struct srt_render_params {
     int32_t max_bounces;    /* MAXBOUNCES (Raytracer.cpp:32), >= 0 */
     uint32_t seed;          /* RNG seed; the reference names only srand(0) (:263) */
     uint32_t flags;         /* SRT_RENDER_* */
+    /* progressive-resolution blocks of renderArea (:233-248): one ray per steps x steps block,
+     * its colour replicated into every pixel of the block.  0 or 1 = one ray per pixel.  The
+     * reference anchors blocks at the start of each worker's column stripe (:235, :338-340):
+     * stripe_width = that stripe width (`div`), 0 = a single stripe (anchors at x = 0). */
+    int32_t steps;
+    int32_t stripe_width;
+    int32_t selected_object; /* list index of selectedObject (:53) for the preview highlight; -1 = none */
 } srt_render_params;
 
 typedef struct srt_stats {
@@ -162,6 +171,11 @@ int srt_render(srt_context* ctx, const srt_render_params* params);
 int srt_wait(srt_context* ctx);             /* block until the last render finished */
 int srt_poll(srt_context* ctx, int* done);  /* *done = 1 when finished              */
 int srt_get_stats(srt_context* ctx, srt_stats* out);  /* waits for the last render */
+
+/* Picking (Raytracer.cpp:525-541): GetClosestObject(camera.position, GetRayDirection(camera, x, y))
+ * with y in SCENE rows (the reference flips the mouse y first, :532).  *object_index = list
+ * index of the hit object or -1.  Synchronous. */
+int srt_pick(srt_context* ctx, int x, int y, int* object_index);
 
 /* ---- buffers the worker writes ------------------------------------------------- */
 /* Copies memory rows [row_begin,row_end) into dst (dst points at row_begin's first

@@ -233,6 +233,8 @@ typedef struct octx {
     int32_t fov;           /* FOV :31 */
     int32_t max_bounces;   /* MAXBOUNCES :32 */
     int32_t pow_mode;
+    int32_t simpledraw;      /* SIMPLEDRAW :35 */
+    int32_t selected_object; /* selectedObject :53 as a list index, -1 = NULL */
     /* rand() replacement: see include/srt_defs.h */
     uint32_t rng_key, rng_draws;
     uint64_t rays;
@@ -332,11 +334,34 @@ static f3 get_ray_direction(const srt_camera* cam, int32_t W, int32_t H, int32_t
 
 static const srt_material* mat_of(const octx* c, int idx) { return &c->objects[idx].material; }
 
+/* template smoothstep (Common.hpp:352-365) */
+static float smoothstep_t(float edge0, float edge1, float x) {
+    if (x < edge0) return 0;
+    if (x >= edge1) return 1;
+    x = (x - edge0) / (edge1 - edge0);
+    return x * x * (3 - 2 * x);
+}
+
 /* RaytraceScene, SIMPLEDRAW == false (Raytracer.cpp:141-146, 162-185, 212) */
 static col raytrace_scene(octx* c, f3 rayOrigin, f3 rayDirection) {
     rayhitobject hit = get_closest_object(c, rayOrigin, rayDirection); /* :142 */
     if (!hit.rayHit.valid) {
         return get_environment_color(c, rayDirection);                 /* :143-145 */
+    }
+    if (c->simpledraw) { /* :147-160 */
+        col reflectedColor = get_environment_color(c, f3_reflect(rayDirection, hit.rayHit.normal)); /* :148 */
+        float k = mat_of(c, hit.objectReference)->specular_amount;                                 /* :149 */
+        float s = mat_of(c, hit.objectReference)->smoothness;                                      /* :150 */
+        float fresnal = 0;                                                                         /* :152 */
+        if (hit.objectReference == c->selected_object) {                                           /* :153 */
+            fresnal = 1 - f3_dot(f3_neg(hit.rayHit.normal), rayDirection);                         /* :154 */
+            fresnal = maxf_t(fresnal, 0.0f);                                                       /* :155 */
+            fresnal = smoothstep_t(0.0f, 0.5f, fresnal);                                           /* :156 */
+        }
+        col base = col_rgb(mat_of(c, hit.objectReference)->base_color);
+        col emis = col_rgb(mat_of(c, hit.objectReference)->emissive_color);
+        return col_lerp(col_add(col_add(col_muls(base, (1 - k)), col_muls(col_muls(reflectedColor, k), s)), emis),
+                        col_make(3, 3, 0, 0), fresnal);                                            /* :159 */
     }
     col incomingLight = col_rgb(mat_of(c, hit.objectReference)->emissive_color); /* :162 */
     col hitColor = col_rgb(mat_of(c, hit.objectReference)->base_color);          /* :163 */
@@ -392,8 +417,18 @@ typedef struct worker {
     srt_oracle_job* job;
     int32_t minX, maxX, minY, maxY; /* scene coordinates, max exclusive */
     int x_outer;                    /* reference walk order :235-237 */
+    int literal_blocks;             /* run renderArea's own block loop nest (SPLIT_REF_COLS + steps) */
     uint64_t rays;
 } worker;
+
+/* Anchor of the steps x steps block that pixel (x, y) belongs to in renderArea's walk
+ * (:235-248): blocks start at the worker's minX (= stripe start) and at minY = 0. */
+static void block_anchor(const srt_render_params* p, int x, int y, int* ax, int* ay) {
+    int steps = p->steps > 1 ? p->steps : 1;
+    int s0 = p->stripe_width > 0 ? (x / p->stripe_width) * p->stripe_width : 0;
+    *ax = s0 + ((x - s0) / steps) * steps;
+    *ay = (y / steps) * steps;
+}
 
 static void render_pixel(octx* c, const srt_oracle_job* job, int x, int y) {
     const srt_render_params* p = &job->params;
@@ -404,9 +439,11 @@ static void render_pixel(octx* c, const srt_oracle_job* job, int x, int y) {
     f3 origin = f3_make(cam->position[0], cam->position[1], cam->position[2]);
     for (uint32_t s = 0; s < p->sample_count; s++) {
         uint32_t frame = p->first_sample + s;
-        c->rng_key = srt_rng_key(p->seed, (uint32_t)(x + y * W), frame);
+        int ax, ay;
+        block_anchor(p, x, y, &ax, &ay); /* the block's ray is traced through its anchor pixel (:239) */
+        c->rng_key = srt_rng_key(p->seed, (uint32_t)(ax + ay * W), frame);
         c->rng_draws = 0;
-        f3 rayDirection = get_ray_direction(cam, W, H, cam->fov_degrees, x, y); /* :239 */
+        f3 rayDirection = get_ray_direction(cam, W, H, cam->fov_degrees, ax, ay); /* :239 */
         col color = raytrace_scene(c, origin, rayDirection);                     /* :240 */
         int setFrame = (s == 0) && (p->flags & SRT_RENDER_RESET);
         colorBuffer = accumulate(colorBuffer, color, setFrame, frame);           /* :246 -> :63 */
@@ -431,6 +468,32 @@ static void* worker_main(void* arg) {
     c.fov = job->camera->fov_degrees;
     c.max_bounces = job->params.max_bounces;
     c.pow_mode = job->pow_mode;
+    c.simpledraw = (job->params.flags & SRT_RENDER_PREVIEW) != 0;
+    c.selected_object = job->params.selected_object;
+    if (w->literal_blocks) { /* renderArea's own loop nest, :235-248, for ONE frame */
+        const srt_render_params* p = &job->params;
+        const int W = job->width, H = job->height, steps = p->steps > 1 ? p->steps : 1;
+        const srt_camera* cam = job->camera;
+        f3 origin = f3_make(cam->position[0], cam->position[1], cam->position[2]);
+        for (int i = w->minX; i < w->maxX; i += steps) {
+            for (int j = w->minY; j < w->maxY; j += steps) {
+                c.rng_key = srt_rng_key(p->seed, (uint32_t)(i + j * W), p->first_sample);
+                c.rng_draws = 0;
+                col color = raytrace_scene(&c, origin, get_ray_direction(cam, W, H, cam->fov_degrees, i, j));
+                for (int i1 = 0; i1 < steps && i + i1 < w->maxX; i1++) {
+                    for (int j1 = 0; j1 < steps && j + j1 < w->maxY; j1++) {
+                        float* cb = job->accumulator + ((size_t)(i + i1) + (size_t)(j + j1) * W) * 4;
+                        col buf = {cb[0], cb[1], cb[2], cb[3]};
+                        buf = accumulate(buf, color, (p->flags & SRT_RENDER_RESET) != 0, p->first_sample);
+                        cb[0] = buf.r, cb[1] = buf.g, cb[2] = buf.b, cb[3] = buf.a;
+                        if (job->framebuffer) job->framebuffer[(size_t)(H - 1 - (j + j1)) * W + (i + i1)] = tonemap_pack(buf);
+                    }
+                }
+            }
+        }
+        w->rays = c.rays;
+        return NULL;
+    }
     if (w->x_outer) {
         for (int x = w->minX; x < w->maxX; x++)
             for (int y = w->minY; y < w->maxY; y++) render_pixel(&c, job, x, y);
@@ -475,6 +538,8 @@ int srt_oracle_render(srt_oracle_job* job) {
             ws[n].minY = y0;
             ws[n].maxY = y1;
             ws[n].x_outer = 1;
+            /* with block replication the literal loop nest is used (one frame, full height) */
+            ws[n].literal_blocks = p->steps > 1 && p->sample_count == 1 && y0 == 0 && y1 == H;
             n++;
         }
     } else {

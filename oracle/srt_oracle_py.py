@@ -23,6 +23,7 @@ SPLIT_ROWS = 0
 SPLIT_REF_COLS = 1
 RENDER_RESET = 1
 RENDER_COUNT_RAYS = 2
+RENDER_PREVIEW = 4
 
 OBJ_NONE, OBJ_SPHERE, OBJ_BOX = 0, 1, 2
 
@@ -76,6 +77,9 @@ class RenderParams(C.Structure):
         ("max_bounces", C.c_int32),
         ("seed", C.c_uint32),
         ("flags", C.c_uint32),
+        ("steps", C.c_int32),
+        ("stripe_width", C.c_int32),
+        ("selected_object", C.c_int32),
     ]
 
 
@@ -217,7 +221,7 @@ def load_scene_json_py(path):
 
 def render(objects, count, env, cam, width, height, *, spp=1, bounces=4, seed=0, first_sample=1,
            reset=True, rows=None, accumulator=None, pow_mode=POW_SHARED, threads=None,
-           split=SPLIT_ROWS):
+           split=SPLIT_ROWS, preview=False, steps=1, stripe_width=0, selected=-1):
     """Run the oracle. Returns (framebuffer uint32 [H,W] bottom-up, accumulator float32
     [H,W,4] scene rows, rays)."""
     if threads is None:
@@ -234,7 +238,8 @@ def render(objects, count, env, cam, width, height, *, spp=1, bounces=4, seed=0,
     job.camera = C.pointer(cam)
     job.width, job.height = width, height
     rb, re = rows if rows is not None else (0, height)
-    job.params = RenderParams(rb, re, first_sample, spp, bounces, seed, RENDER_RESET if reset else 0)
+    job.params = RenderParams(rb, re, first_sample, spp, bounces, seed,
+                              (RENDER_RESET if reset else 0) | (RENDER_PREVIEW if preview else 0), steps, stripe_width, selected)
     job.accumulator = accumulator.ctypes.data_as(C.POINTER(C.c_float))
     job.framebuffer = fb.ctypes.data_as(C.POINTER(C.c_uint32))
     job.pow_mode = pow_mode

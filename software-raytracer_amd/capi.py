@@ -15,15 +15,15 @@ _LIB = os.path.join(_PKG, "libsrt_pathtrace.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_OOM = range(6)
 OBJ_NONE, OBJ_SPHERE, OBJ_BOX = 0, 1, 2
-RENDER_RESET, RENDER_COUNT_RAYS = 1, 2
-ABI_VERSION = 1
+RENDER_RESET, RENDER_COUNT_RAYS, RENDER_PREVIEW = 1, 2, 4
+ABI_VERSION = 2
 
 # every symbol include/srt_pathtrace.h declares (tests check the library exports them all)
 EXPORTS = [
     "srt_abi_version", "srt_device_count", "srt_create", "srt_destroy", "srt_last_error",
     "srt_set_scene", "srt_set_environment", "srt_environment_default", "srt_set_camera",
     "srt_set_stream", "srt_bind_output", "srt_device_framebuffer", "srt_device_accumulator",
-    "srt_render", "srt_wait", "srt_poll", "srt_get_stats", "srt_read_framebuffer",
+    "srt_render", "srt_wait", "srt_poll", "srt_get_stats", "srt_pick", "srt_read_framebuffer",
     "srt_read_accumulator", "srt_write_accumulator",
 ]
 
@@ -83,6 +83,9 @@ class RenderParams(C.Structure):
         ("max_bounces", C.c_int32),
         ("seed", C.c_uint32),
         ("flags", C.c_uint32),
+        ("steps", C.c_int32),
+        ("stripe_width", C.c_int32),
+        ("selected_object", C.c_int32),
     ]
 
 
@@ -134,6 +137,7 @@ def load_library():
     L.srt_wait.argtypes = [ctx]
     L.srt_poll.argtypes = [ctx, C.POINTER(C.c_int)]
     L.srt_get_stats.argtypes = [ctx, C.POINTER(Stats)]
+    L.srt_pick.argtypes = [ctx, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.srt_read_framebuffer.argtypes = [ctx, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
     L.srt_read_accumulator.argtypes = [ctx, C.POINTER(C.c_float)]
     L.srt_write_accumulator.argtypes = [ctx, C.POINTER(C.c_float)]
@@ -219,10 +223,11 @@ class PathTracer:
         self._ck(self.L.srt_bind_output(self._h, C.c_void_p(d_framebuffer or 0), C.c_void_p(d_accumulator or 0)))
 
     # ---- hot path --------------------------------------------------------------------
-    def render(self, *, spp=1, bounces=4, seed=0, first_sample=1, reset=True, rows=None, count_rays=False):
+    def render(self, *, spp=1, bounces=4, seed=0, first_sample=1, reset=True, rows=None, count_rays=False,
+               preview=False, steps=1, stripe_width=0, selected=-1):
         rb, re = rows if rows is not None else (0, self.height)
-        flags = (RENDER_RESET if reset else 0) | (RENDER_COUNT_RAYS if count_rays else 0)
-        p = RenderParams(rb, re, first_sample, spp, bounces, seed, flags)
+        flags = (RENDER_RESET if reset else 0) | (RENDER_COUNT_RAYS if count_rays else 0) | (RENDER_PREVIEW if preview else 0)
+        p = RenderParams(rb, re, first_sample, spp, bounces, seed, flags, steps, stripe_width, selected)
         self._ck(self.L.srt_render(self._h, C.byref(p)))
 
     def wait(self):
@@ -232,6 +237,12 @@ class PathTracer:
         d = C.c_int(0)
         self._ck(self.L.srt_poll(self._h, C.byref(d)))
         return bool(d.value)
+
+    def pick(self, x, y):
+        """Raytracer.cpp:525-541; y in scene rows. Returns the list index or -1."""
+        idx = C.c_int(-2)
+        self._ck(self.L.srt_pick(self._h, int(x), int(y), C.byref(idx)))
+        return idx.value
 
     def stats(self):
         s = Stats()

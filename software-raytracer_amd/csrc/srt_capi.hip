@@ -50,6 +50,7 @@ struct srt_context {
     uint32_t* d_fb = nullptr;
     float4* d_acc = nullptr;
     unsigned long long* d_rays = nullptr;
+    int* d_pick = nullptr;
 
     srt_environment env;
     HostCamera camera;
@@ -158,6 +159,7 @@ int srt_create(int device, int width, int height, srt_context** out) {
     if ((e = hipMalloc((void**)&ctx->d_fb_own, px * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc framebuffer");
     if ((e = hipMalloc((void**)&ctx->d_acc_own, px * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc accumulator");
     if ((e = hipMalloc((void**)&ctx->d_rays, sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc counter");
+    if ((e = hipMalloc((void**)&ctx->d_pick, sizeof(int))) != hipSuccess) return bail(e, "hipMalloc pick");
     if ((e = hipMemsetAsync(ctx->d_fb_own, 0, px * sizeof(uint32_t), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
     if ((e = hipMemsetAsync(ctx->d_acc_own, 0, px * sizeof(float4), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
@@ -179,6 +181,7 @@ int srt_destroy(srt_context* ctx) {
     if (ctx->d_fb_own) (void)hipFree(ctx->d_fb_own);
     if (ctx->d_acc_own) (void)hipFree(ctx->d_acc_own);
     if (ctx->d_rays) (void)hipFree(ctx->d_rays);
+    if (ctx->d_pick) (void)hipFree(ctx->d_pick);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -261,22 +264,10 @@ int srt_device_accumulator(srt_context* ctx, void** d_ptr) {
     return SRT_OK;
 }
 
-int srt_render(srt_context* ctx, const srt_render_params* p) {
-    if (!ctx || !p) return SRT_ERR_INVALID_ARG;
-    if (!ctx->scene_set) return fail(ctx, SRT_ERR_STATE, "srt_render: srt_set_scene has not been called");
-    if (!ctx->camera.set) return fail(ctx, SRT_ERR_STATE, "srt_render: srt_set_camera has not been called");
-    const int W = ctx->width, H = ctx->height;
-    if (p->row_begin < 0 || p->row_end > H || p->row_begin >= p->row_end)
-        return fail(ctx, SRT_ERR_INVALID_ARG, "srt_render: bad row band [%d,%d) for height %d", p->row_begin, p->row_end, H);
-    if (p->first_sample < 1 || p->sample_count < 1 || p->max_bounces < 0)
-        return fail(ctx, SRT_ERR_INVALID_ARG, "srt_render: first_sample/sample_count must be >= 1 and max_bounces >= 0");
-    if (p->sample_count > (1u << 20))
-        return fail(ctx, SRT_ERR_INVALID_ARG, "srt_render: sample_count is limited to 2^20 per call (render in several calls)");
-    if ((uint64_t)p->first_sample + p->sample_count > 0x7fffffffull)
-        return fail(ctx, SRT_ERR_INVALID_ARG, "srt_render: sample index overflows int (ACCUMULATIONFRAMES is an int)");
-    SRT_HIP(ctx, hipSetDevice(ctx->device));
+}  // extern "C"
 
-    srt::KernelParams K;
+static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt::KernelParams& K, size_t& lds_bytes, int& use) {
+    const int W = ctx->width, H = ctx->height;
     memset(&K, 0, sizeof K);
     const srt_camera& c = ctx->camera.cam;
     // frame-constant part of GetRayDirection (Raytracer.cpp:107-115)
@@ -304,12 +295,15 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     K.sample_count = p->sample_count;
     K.max_bounces = p->max_bounces;
     K.seed = p->seed;
-    K.flags = p->flags & (SRT_RENDER_RESET | SRT_RENDER_COUNT_RAYS);
+    K.flags = p->flags & (SRT_RENDER_RESET | SRT_RENDER_COUNT_RAYS | SRT_RENDER_PREVIEW);
+    K.steps = p->steps > 1 ? p->steps : 1;
+    K.stripe_width = p->stripe_width > 0 ? p->stripe_width : 0;
+    K.selected = p->selected_object;
     static const int variant = [] {
         const char* v = getenv("SRT_KERNEL");
         return v ? atoi(v) : 0;
     }();
-    const int use = ctx->variant >= 0 ? ctx->variant : variant;
+    use = ctx->variant >= 0 ? ctx->variant : variant;
     const int img = (use == 2) ? 1 : 0;  // variant 2: plain brute-force image
     const srt::SceneLayout& SL = ctx->layout[img];
     K.nu4 = SL.nu4;
@@ -326,12 +320,38 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     K.framebuffer = ctx->d_fb;
     K.ray_counter = ctx->d_rays;
 
+    lds_bytes = (size_t)(SL.total_vec4 > 0 ? SL.total_vec4 : 1) * sizeof(float4) + srt::WG_SCRATCH_BYTES;
+    return SRT_OK;
+}
+
+extern "C" {
+
+int srt_render(srt_context* ctx, const srt_render_params* p) {
+    if (!ctx || !p) return SRT_ERR_INVALID_ARG;
+    if (!ctx->scene_set) return fail(ctx, SRT_ERR_STATE, "srt_render: srt_set_scene has not been called");
+    if (!ctx->camera.set) return fail(ctx, SRT_ERR_STATE, "srt_render: srt_set_camera has not been called");
+    const int W = ctx->width, H = ctx->height;
+    if (p->row_begin < 0 || p->row_end > H || p->row_begin >= p->row_end)
+        return fail(ctx, SRT_ERR_INVALID_ARG, "srt_render: bad row band [%d,%d) for height %d", p->row_begin, p->row_end, H);
+    if (p->first_sample < 1 || p->sample_count < 1 || p->max_bounces < 0)
+        return fail(ctx, SRT_ERR_INVALID_ARG, "srt_render: first_sample/sample_count must be >= 1 and max_bounces >= 0");
+    if (p->steps < 0 || p->stripe_width < 0)
+        return fail(ctx, SRT_ERR_INVALID_ARG, "srt_render: steps and stripe_width must be >= 0");
+    if (p->sample_count > (1u << 20))
+        return fail(ctx, SRT_ERR_INVALID_ARG, "srt_render: sample_count is limited to 2^20 per call (render in several calls)");
+    if ((uint64_t)p->first_sample + p->sample_count > 0x7fffffffull)
+        return fail(ctx, SRT_ERR_INVALID_ARG, "srt_render: sample index overflows int (ACCUMULATIONFRAMES is an int)");
+    SRT_HIP(ctx, hipSetDevice(ctx->device));
+
+    srt::KernelParams K;
+    size_t lds_bytes = 0;
+    int use = 0;
+    fill_kernel_params(ctx, p, K, lds_bytes, use);
     ctx->count_rays = (p->flags & SRT_RENDER_COUNT_RAYS) != 0;
     if (ctx->count_rays) SRT_HIP(ctx, hipMemsetAsync(ctx->d_rays, 0, sizeof(unsigned long long), ctx->stream));
 
     dim3 grid((unsigned)((W + srt::WG_W - 1) / srt::WG_W), (unsigned)((K.rows + srt::WG_H - 1) / srt::WG_H));
     dim3 block(srt::WG_THREADS);
-    size_t lds_bytes = (size_t)(SL.total_vec4 > 0 ? SL.total_vec4 : 1) * sizeof(float4) + srt::WG_SCRATCH_BYTES;
     SRT_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     // variants are a development aid for in-process A/B timing; all are bit-identical
     if (use == 1)
@@ -365,6 +385,30 @@ int srt_debug_read_stats(unsigned long long* out8) {
     return e == hipSuccess ? 0 : 3;
 }
 #endif
+
+int srt_pick(srt_context* ctx, int x, int y, int* object_index) {
+    if (!ctx || !object_index) return SRT_ERR_INVALID_ARG;
+    if (!ctx->scene_set) return fail(ctx, SRT_ERR_STATE, "srt_pick: srt_set_scene has not been called");
+    if (!ctx->camera.set) return fail(ctx, SRT_ERR_STATE, "srt_pick: srt_set_camera has not been called");
+    SRT_HIP(ctx, hipSetDevice(ctx->device));
+    srt_render_params p{};
+    p.row_begin = 0;
+    p.row_end = ctx->height;
+    p.first_sample = 1;
+    p.sample_count = 1;
+    srt::KernelParams K;
+    size_t lds_bytes = 0;
+    int use = 0;
+    fill_kernel_params(ctx, &p, K, lds_bytes, use);
+    int* d_out = ctx->d_pick;
+    hipLaunchKernelGGL(srt::pick_kernel, dim3(1), dim3(64), lds_bytes, ctx->stream, K, x, y, d_out);
+    SRT_HIP(ctx, hipGetLastError());
+    int idx = -1;
+    SRT_HIP(ctx, hipMemcpyAsync(&idx, d_out, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *object_index = idx;
+    return SRT_OK;
+}
 
 int srt_wait(srt_context* ctx) {
     if (!ctx) return SRT_ERR_INVALID_ARG;

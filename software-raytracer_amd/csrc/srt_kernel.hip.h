@@ -53,6 +53,7 @@ struct KernelParams {
     uint32_t first_sample, sample_count;
     int32_t max_bounces;
     uint32_t seed, flags;
+    int32_t steps, stripe_width, selected;  // progressive blocks (:233-248), selectedObject (:53)
     // scene image layout (srt_scene_image.h)
     int32_t nu4, nc, K, nsT, nb;
     int32_t off_bounds, off_box, off_mat;
@@ -400,9 +401,19 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     const int x = in_range ? tx : 0, y = in_range ? (P.y0 + ty) : P.y0;
     const uint32_t pixel = (uint32_t)(x + y * W);
 
+    // ---- progressive blocks (Raytracer.cpp:235-248): the ray of a steps x steps block goes
+    // through the block's anchor pixel; blocks start at the worker stripe's first column.
+    int ax = x, ay = y;
+    if (P.steps > 1) {
+        const int s0 = P.stripe_width > 0 ? (x / P.stripe_width) * P.stripe_width : 0;
+        ax = s0 + ((x - s0) / P.steps) * P.steps;
+        ay = (y / P.steps) * P.steps;
+    }
+    const uint32_t rng_pixel = (uint32_t)(ax + ay * W);
+
     // ---- GetRayDirection (Raytracer.cpp:106-122) ----------------------------------
-    float nX = ((float)x / (float)W) * 2 - 1;
-    float nY = ((float)y / (float)H) * 2 - 1;
+    float nX = ((float)ax / (float)W) * 2 - 1;
+    float nY = ((float)ay / (float)H) * 2 - 1;
     V3 u = v3(P.right_rd[0] * nX, P.right_rd[1] * nX, P.right_rd[2] * nX);
     V3 vv = v3(P.up_ld[0] * nY, P.up_ld[1] * nY, P.up_ld[2] * nY);
     const V3 dir0 = normalized(v3((u.x + vv.x) + P.fwd_clip[0], (u.y + vv.y) + P.fwd_clip[1], (u.z + vv.z) + P.fwd_clip[2]));
@@ -448,11 +459,38 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
 
     // ---- pixels whose colour does not depend on the sample: finish them right here --------
     //  primary miss -> env(dir0) every frame (:143-145); MAXBOUNCES == 0 -> EmissiveColor (:162,212)
-    const bool traced = in_range && h0.prim >= 0 && B > 0;
+    //  SIMPLEDRAW -> the one-ray preview shader (:147-160), no random draws
+    const bool preview = (P.flags & 4u) != 0;
+    const bool traced = in_range && h0.prim >= 0 && B > 0 && !preview;
     if (in_range && !traced) {
         RGB c;
         if (h0.prim < 0) {
             c = environment(P, dir0);
+        } else if (preview) {
+            float4 m0 = S.mat(h0.prim, 0), m1 = S.mat(h0.prim, 1);
+            float k2 = 2 * dot3(dir0, h0.n);  // rayDirection.Reflect(normal), Common.hpp:163-165
+            RGB refl = environment(P, v3(dir0.x - h0.n.x * k2, dir0.y - h0.n.y * k2, dir0.z - h0.n.z * k2));  // :148
+            const float k = m0.y, sm = m0.x;  // :149-150
+            float fresnal = 0;
+            if (S.order(h0.prim) == P.selected) {  // :153
+                fresnal = 1 - dot3(v3(h0.n.x * -1, h0.n.y * -1, h0.n.z * -1), dir0);  // :154
+                fresnal = tmax(fresnal, 0.0f);                                       // :155
+                if (fresnal < 0.0f) {                                                // smoothstep, Common.hpp:352-365
+                    fresnal = 0;
+                } else if (fresnal >= 0.5f) {
+                    fresnal = 1;
+                } else {
+                    fresnal = (fresnal - 0.0f) / (0.5f - 0.0f);
+                    fresnal = fresnal * fresnal * (3 - 2 * fresnal);
+                }
+            }
+            RGB base{clamp0(m0.z), clamp0(m0.w), clamp0(m1.x)}, emis{clamp0(m1.y), clamp0(m1.z), clamp0(m1.w)};
+            const float omk = 1 - k;
+            // BaseColor * (1-k) + reflectedColor * k * s + EmissiveColor   (:159)
+            RGB a{clamp0(clamp0(clamp0(base.r * omk) + clamp0(clamp0(refl.r * k) * sm)) + emis.r),
+                  clamp0(clamp0(clamp0(base.g * omk) + clamp0(clamp0(refl.g * k) * sm)) + emis.g),
+                  clamp0(clamp0(clamp0(base.b * omk) + clamp0(clamp0(refl.b * k) * sm)) + emis.b)};
+            c = color_lerp(a, RGB{3.0f, 3.0f, 0.0f}, fresnal);
         } else {
             float4 m1 = S.mat(h0.prim, 1);
             c = RGB{clamp0(m1.y), clamp0(m1.z), clamp0(m1.w)};
@@ -473,7 +511,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     const unsigned long long hitmask = __builtin_amdgcn_ballot_w64(traced);
     const int n_hit = __builtin_popcountll(hitmask);
     if (n_hit > 0) {
-        float* rec = S.pix;  // [64][12]: dir0, n0, p0, prim0, pixel
+        float* rec = S.pix;  // [64][12]: dir0, n0, p0, prim0, rng pixel (block anchor), output pixel
         if (traced) {
             const int slot = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hitmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hitmask, 0u));
             float* r = rec + slot * 12;
@@ -481,7 +519,8 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             r[3] = h0.n.x, r[4] = h0.n.y, r[5] = h0.n.z;
             r[6] = h0.p.x, r[7] = h0.p.y, r[8] = h0.p.z;
             r[9] = __int_as_float(h0.prim);
-            r[10] = __uint_as_float(pixel);
+            r[10] = __uint_as_float(rng_pixel);
+            r[11] = __uint_as_float(pixel);
         }
         const int depth = (64 * RING_DEPTH) / n_hit;  // ring entries per slot (>= RING_DEPTH)
         float4* ring = S.ring;                        // [depth][n_hit] of (r, g, b, tag)
@@ -493,7 +532,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         uint32_t own_pixel = 0, own_done = owner ? 0u : count;  // samples folded so far
         float4 acc = make_float4(0, 0, 0, 0);
         if (owner) {
-            own_pixel = __float_as_uint(rec[lane * 12 + 10]);
+            own_pixel = __float_as_uint(rec[lane * 12 + 11]);
             if (!reset) acc = P.accumulator[own_pixel];
         }
 
@@ -635,6 +674,25 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
         if (lane == 0 && tot) atomicAdd(P.ray_counter, tot);
     }
+}
+
+// Picking (Raytracer.cpp:525-541): one wave, every lane traces the same ray.
+__global__ void __launch_bounds__(64) pick_kernel(const KernelParams P, int px, int py, int* out_index) {
+    extern __shared__ float4 lds_scene[];
+    for (int i = threadIdx.x; i < P.scene_vec4; i += 64) lds_scene[i] = P.scene[i];
+    __syncthreads();
+    char* scratch = reinterpret_cast<char*>(lds_scene + P.scene_vec4);
+    Lds S{lds_scene, P.nu4, P.nc, P.K, P.nsT, P.nb, P.off_bounds, P.off_box, P.off_mat,
+          reinterpret_cast<unsigned long long*>(scratch), reinterpret_cast<unsigned short*>(scratch + 64 * 8),
+          reinterpret_cast<float*>(scratch + 64 * 8 + WORK_MAX * 2),
+          reinterpret_cast<float4*>(scratch + 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4)};
+    float nX = ((float)px / (float)P.width) * 2 - 1;
+    float nY = ((float)py / (float)P.height) * 2 - 1;
+    V3 u = v3(P.right_rd[0] * nX, P.right_rd[1] * nX, P.right_rd[2] * nX);
+    V3 vv = v3(P.up_ld[0] * nY, P.up_ld[1] * nY, P.up_ld[2] * nY);
+    const V3 dir = normalized(v3((u.x + vv.x) + P.fwd_clip[0], (u.y + vv.y) + P.fwd_clip[1], (u.z + vv.z) + P.fwd_clip[2]));
+    const Hit h = closest_hit(S, v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]), dir, true);
+    if (threadIdx.x == 0) *out_index = h.prim >= 0 ? S.order(h.prim) : -1;
 }
 
 }  // namespace srt

@@ -19,7 +19,7 @@ EXPORTS = [
     "srt_host_format_double", "srt_host_rotate_about_axis", "srt_host_last_error",
     "srt_host_renderer_create", "srt_host_renderer_destroy", "srt_host_renderer_set_scene",
     "srt_host_renderer_set_band", "srt_host_renderer_settings", "srt_host_renderer_set_camera",
-    "srt_host_renderer_invalidate", "srt_host_renderer_render_frame", "srt_host_renderer_render_samples",
+    "srt_host_renderer_invalidate", "srt_host_renderer_mode", "srt_host_renderer_pick", "srt_host_renderer_render_frame", "srt_host_renderer_render_samples",
     "srt_host_renderer_accumulation_frames", "srt_host_renderer_wait", "srt_host_renderer_read_framebuffer",
     "srt_host_renderer_read_accumulator", "srt_host_renderer_stats", "srt_host_renderer_handle",
 ]
@@ -75,6 +75,8 @@ def load_library():
     L.srt_host_renderer_set_band.argtypes = [vp, C.c_int, C.c_int]
     L.srt_host_renderer_settings.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_uint32]
     L.srt_host_renderer_set_camera.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.srt_host_renderer_mode.argtypes = [vp, C.c_int, C.c_float, C.c_int]
+    L.srt_host_renderer_pick.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.srt_host_renderer_invalidate.argtypes = [vp]
     L.srt_host_renderer_invalidate.restype = None
     L.srt_host_renderer_render_frame.argtypes = [vp]
@@ -202,6 +204,14 @@ class Renderer:
         p = (C.c_float * 3)(*[float(x) for x in position])
         b = (C.c_float * 9)(*[float(x) for x in basis9])
         self._ck(self.L.srt_host_renderer_set_camera(self._h, p, b))
+
+    def mode(self, simpledraw=True, screen_scale=0.5, selected=-1):
+        self._ck(self.L.srt_host_renderer_mode(self._h, 1 if simpledraw else 0, float(screen_scale), int(selected)))
+
+    def pick(self, mouse_x, mouse_y):
+        idx = C.c_int(-2)
+        self._ck(self.L.srt_host_renderer_pick(self._h, mouse_x, mouse_y, C.byref(idx)))
+        return idx.value
 
     def invalidate(self):
         self.L.srt_host_renderer_invalidate(self._h)

@@ -137,6 +137,15 @@ int srt_host_renderer_settings(srt_host_renderer* h, int fov, int max_bounces, i
     h->r->Invalidate();
     return 0;
 }
+// SIMPLEDRAW (:35), SCREEN_SCALE (:30), selectedObject (:53)
+int srt_host_renderer_mode(srt_host_renderer* h, int simpledraw, float screen_scale, int selected_object) {
+    h->r->SIMPLEDRAW = simpledraw != 0;
+    h->r->SCREEN_SCALE = screen_scale;
+    h->r->selectedObject = selected_object;
+    h->r->Invalidate();
+    return 0;
+}
+int srt_host_renderer_pick(srt_host_renderer* h, int mouse_x, int mouse_y, int* index) { SRT_HOST_TRY(h, *index = h->r->Pick(mouse_x, mouse_y)) }
 int srt_host_renderer_set_camera(srt_host_renderer* h, const float* pos, const float* right_up_forward) {
     Transform& t = h->r->camera;
     t.position = Vec3(pos[0], pos[1], pos[2]);

@@ -53,20 +53,21 @@ void PathTraceRenderer::push_camera() {
 }
 
 bool PathTraceRenderer::RenderFrame() {
-    bool setFrame;
-    if (doSetFrame_) {
-        // loop iteration 1 after an edit (Raytracer.cpp:577-582): setFrame, ACC = 1,
-        // progressiveResolutionScaler = 1/4 -> a quarter-resolution frame (not rendered here)
-        ACCUMULATIONFRAMES = 1;
-        doSetFrame_ = false;
-        if (ACCUMULATIONFRAMES == TARGETFRAMES) return false;  // :572-574
-        // iteration 2 (:584-590): scaler != 1 -> setFrame = true; ACC += 1
-        setFrame = true;
-        ACCUMULATIONFRAMES += 1;
+    if (first_frame_) {
+        first_frame_ = false;  // workers start with the initial globals (:30-35,47-48,271)
     } else {
         if (ACCUMULATIONFRAMES == TARGETFRAMES) return false;  // :572-574
-        setFrame = false;                                      // :585
-        ACCUMULATIONFRAMES += 1;                               // :590
+        if (doSetFrame_) {                                     // :576-582
+            setFrame = true;
+            ACCUMULATIONFRAMES = 1;
+            progressiveResolutionScaler = 1.0f / 4.0f;
+            doSetFrame_ = false;
+        } else {                                               // :583-590
+            setFrame = false;
+            if (progressiveResolutionScaler != 1) setFrame = true;
+            progressiveResolutionScaler = 1;
+            ACCUMULATIONFRAMES += SIMPLEDRAW ? 0 : 1;
+        }
     }
     push_camera();
     srt_render_params p{};
@@ -76,17 +77,28 @@ bool PathTraceRenderer::RenderFrame() {
     p.sample_count = 1;
     p.max_bounces = MAXBOUNCES < 0 ? 0 : MAXBOUNCES;  // :475
     p.seed = seed;
-    p.flags = setFrame ? SRT_RENDER_RESET : 0;
+    p.flags = (setFrame ? SRT_RENDER_RESET : 0u) | (SIMPLEDRAW ? SRT_RENDER_PREVIEW : 0u);
+    p.steps = (int)ceil(1 / ((float)SCREEN_SCALE * progressiveResolutionScaler));  // :233
+    p.stripe_width = (int)ceil(width_ / (THREADS)) + 1;                             // :330 (integer divide first)
+    p.selected_object = selectedObject;
     check(srt_render(ctx_, &p), "srt_render");
-    next_clean_sample_ = (uint32_t)ACCUMULATIONFRAMES + 1;
+    clean_reset_ = true;
     return true;
+}
+
+int PathTraceRenderer::Pick(int mouse_x, int mouse_y) {
+    push_camera();
+    int idx = -1;
+    check(srt_pick(ctx_, mouse_x, height_ - mouse_y, &idx), "srt_pick");  // :532 y = SCREEN_HEIGHT - y
+    return idx;
 }
 
 void PathTraceRenderer::RenderSamples(uint32_t count, bool count_rays) {
     if (count == 0) return;
-    bool reset = doSetFrame_;
+    bool reset = doSetFrame_ || clean_reset_;
     if (reset) next_clean_sample_ = 1;
     doSetFrame_ = false;
+    clean_reset_ = false;
     push_camera();
     srt_render_params p{};
     p.row_begin = row_begin_;
@@ -96,9 +108,14 @@ void PathTraceRenderer::RenderSamples(uint32_t count, bool count_rays) {
     p.max_bounces = MAXBOUNCES < 0 ? 0 : MAXBOUNCES;
     p.seed = seed;
     p.flags = (reset ? SRT_RENDER_RESET : 0) | (count_rays ? SRT_RENDER_COUNT_RAYS : 0);
+    p.steps = 1;
+    p.selected_object = -1;
     check(srt_render(ctx_, &p), "srt_render");
     next_clean_sample_ += count;
     ACCUMULATIONFRAMES = (int)(next_clean_sample_ - 1);
+    first_frame_ = false;
+    setFrame = false;
+    progressiveResolutionScaler = 1;
 }
 
 void PathTraceRenderer::Wait() { check(srt_wait(ctx_), "srt_wait"); }

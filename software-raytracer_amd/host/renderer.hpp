@@ -54,11 +54,17 @@ class RendererError : public std::runtime_error {
 // One GPU, one image (or one row band of it).
 class PathTraceRenderer {
    public:
-    // the reference's mutable globals (Raytracer.cpp:31-34) as members
+    // the reference's mutable globals (Raytracer.cpp:30-35,47-48,53) as members, same defaults
+    float SCREEN_SCALE = .5f;
     int FOV = 55;
     int MAXBOUNCES = 2;
     int TARGETFRAMES = 4096;
     int ACCUMULATIONFRAMES = 1;
+    bool SIMPLEDRAW = true;
+    float progressiveResolutionScaler = 1;  // :47, set to 1 at :271
+    bool setFrame = false;                  // :48
+    int selectedObject = -1;                // :53 as an index into ObjectsToRender, -1 = NULL
+    static constexpr int THREADS = 16;      // :28 — only used for the block anchoring of :235,330
     uint32_t seed = 0;  // the reference only ever names srand(0) (:263)
     Transform camera;   // :295-297
 
@@ -79,14 +85,17 @@ class PathTraceRenderer {
     // doSetFrame = true: any camera / object / setting edit (:391,453,461,469,476,497,522)
     void Invalidate() { doSetFrame_ = true; }
 
-    // One pass of the frame loop's accumulate state machine (:572-595), path-trace mode,
-    // followed by releasing the workers for ONE frame.  Reproduces the reference's sample
-    // indices and setFrame flags including its quirk: after an edit the first full
-    // resolution frame is rendered with setFrame == true AND ACCUMULATIONFRAMES == 2.
-    // (The 1/4-resolution frame the reference shows first is the "progressive blocks" row
-    // of SURVEY §8f and is not rendered.)  Returns false when nothing was launched
-    // (ACCUMULATIONFRAMES == TARGETFRAMES, :572-574).
+    // One iteration of the reference's frame loop as far as rendering is concerned: the
+    // accumulate state machine (:572-590) followed by releasing the workers for ONE frame
+    // (:592-595) with the globals as they then stand — including SIMPLEDRAW (preview shader),
+    // the steps x steps progressive blocks (steps = ceil(1/(SCREEN_SCALE*scaler)), :233) anchored
+    // at the 16 worker stripes (:330-340), and the reference's quirk that the first full
+    // resolution frame after an edit has setFrame == true AND ACCUMULATIONFRAMES == 2.
+    // The very first call renders with the start-up globals, as the workers do before the
+    // loop's first pass.  Returns false when nothing was launched (ACC == TARGETFRAMES, :572).
     bool RenderFrame();
+    // Picking (:525-541): x, y in window coordinates (y down, as the mouse reports it)
+    int Pick(int mouse_x, int mouse_y);
 
     // Clean sequence used by benchmarks and fixtures: `count` further samples in ONE
     // launch; the first call after Invalidate() starts at sample 1 with reset.
@@ -105,8 +114,9 @@ class PathTraceRenderer {
     srt_context* ctx_ = nullptr;
     int width_, height_;
     int row_begin_, row_end_;
-    bool doSetFrame_ = true;  // a fresh renderer starts like the app after its first edit
-    bool ui_after_reset_ = false;
+    bool doSetFrame_ = false;
+    bool first_frame_ = true;
+    bool clean_reset_ = true;  // RenderSamples: next call starts at sample 1 with reset
     uint32_t next_clean_sample_ = 1;
 };
 

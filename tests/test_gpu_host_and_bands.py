@@ -157,12 +157,14 @@ def test_host_renderer_sequences(srt, oracle):
     ofb, oacc, _ = _oracle_frame(oracle, objs, n, w, h, spp=5, bounces=3, seed=4)
     assert np.array_equal(r.framebuffer(), ofb) and np.array_equal(r.accumulator().view(np.uint32), oacc.view(np.uint32))
     assert r.accumulation_frames == 5 and r.stats().path_samples == w * h * 3
-    # UI sequence: edit -> frames f=2 (reset), 3, 4, 5, 6 then stop at TARGETFRAMES
-    r.invalidate()
+    # UI sequence in path-trace mode at full scale (Raytracer.cpp:572-590): after an edit the loop
+    # renders f=1 at 1/4 resolution (steps 4, reset), then f=2 full resolution WITH reset (the
+    # quirk), then f=3..6 accumulating, then stops at TARGETFRAMES.
+    r.mode(simpledraw=False, screen_scale=1.0)
     launched = 0
     while r.render_frame():
         launched += 1
-    assert launched == 5 and r.accumulation_frames == 6 and not r.render_frame()
+    assert launched == 6 and r.accumulation_frames == 6 and not r.render_frame()
     _, oacc, _ = _oracle_frame(oracle, objs, n, w, h, spp=1, bounces=3, seed=4, first_sample=2, reset=True)
     ofb, oacc, _ = _oracle_frame(oracle, objs, n, w, h, spp=4, bounces=3, seed=4, first_sample=3, reset=False, accumulator=oacc)
     assert np.array_equal(r.framebuffer(), ofb) and np.array_equal(r.accumulator().view(np.uint32), oacc.view(np.uint32))
@@ -196,3 +198,57 @@ def test_full_size_properties_1080p(srt, oracle):
     pt.render(spp=12, bounces=8, seed=0, first_sample=21, reset=False)
     assert np.array_equal(pt.framebuffer(), a)
     assert (a >> 24 == 0).all()  # alpha byte is always 0 (Raytracer.cpp:74)
+
+
+@pytest.mark.parametrize("name", ["Scene1", "Scene3", "Scene_indirect"])
+def test_preview_steps_and_picking(srt, oracle, name):
+    """SIMPLEDRAW shader (:147-160), progressive blocks (:233-248), picking (:525-541)."""
+    w, h = 150, 84
+    pt, objs, n = _pt(srt, name, w, h)
+    oarr = C.cast(objs, C.POINTER(oracle.Object))
+    env, cam = oracle.default_environment(), oracle.default_camera()
+    div = w // 16 + 1
+    cases = [dict(preview=True), dict(preview=True, selected=5), dict(preview=True, steps=2, stripe_width=div),
+             dict(preview=False, steps=4, stripe_width=div), dict(preview=False, steps=8, stripe_width=0),
+             dict(preview=True, steps=3, stripe_width=div, selected=n - 1)]
+    for kw in cases:
+        pt.render(spp=2, bounces=4, seed=3, **kw)
+        ofb, oacc, _ = oracle.render(oarr, n, env, cam, w, h, spp=2, bounces=4, seed=3, **kw)
+        assert np.array_equal(pt.framebuffer(), ofb), kw
+        assert np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32)), kw
+    # picking equals the oracle's GetClosestObject on the same pixel ray
+    import ctypes
+    d, nn, pp, t = (ctypes.c_float * 3)(), (ctypes.c_float * 3)(), (ctypes.c_float * 3)(), ctypes.c_float()
+    origin = (ctypes.c_float * 3)(0, 0, 0)
+    hits = 0
+    for (x, y) in [(0, 0), (75, 42), (20, 10), (140, 70), (75, 5), (33, 33), (100, 20), (149, 83)]:
+        oracle.lib().srt_oracle_ray_direction(ctypes.byref(cam), w, h, x, y, d)
+        idx = oracle.lib().srt_oracle_closest(oarr, n, origin, d, nn, pp, ctypes.byref(t))
+        assert pt.pick(x, y) == idx
+        hits += idx >= 0
+    assert hits >= 2
+    pt.close()
+
+
+def test_host_renderer_default_ui_loop(srt, oracle):
+    """A fresh PathTraceRenderer behaves like the reference at start-up: SIMPLEDRAW preview at
+    SCREEN_SCALE .5 -> steps 2 blocks anchored at 16 stripes; an edit triggers a steps-8 frame."""
+    w, h = 128, 72
+    scene = srt.host.Scene(scene_path("Scene1"))
+    objs, n = scene.objects_copy()
+    oarr = C.cast(objs, C.POINTER(oracle.Object))
+    env, cam = oracle.default_environment(), oracle.default_camera()
+    r = srt.host.Renderer(w, h)
+    r.set_scene(scene)
+    div = w // 16 + 1
+    assert r.render_frame()  # start-up globals: ACC 1, no reset, steps = ceil(1/.5) = 2
+    ofb, oacc, _ = oracle.render(oarr, n, env, cam, w, h, spp=1, bounces=2, seed=0, preview=True, steps=2, stripe_width=div, reset=False)
+    assert np.array_equal(r.framebuffer(), ofb) and np.array_equal(r.accumulator().view(np.uint32), oacc.view(np.uint32))
+    assert r.render_frame()  # SetScene raised doSetFrame: setFrame, scaler 1/4 -> steps = ceil(1/(.5*.25)) = 8
+    ofb, oacc, _ = oracle.render(oarr, n, env, cam, w, h, spp=1, bounces=2, seed=0, preview=True, steps=8, stripe_width=div, reset=True)
+    assert np.array_equal(r.framebuffer(), ofb)
+    assert r.render_frame() and r.accumulation_frames == 1  # preview never advances ACCUMULATIONFRAMES (:590)
+    # picking through the host class uses window coordinates (y down)
+    idx = r.pick(64, 36)
+    assert idx == 64  # the big ball at (0,0,5) is object 64 of Scene1 and fills the centre
+    r.close()

@@ -228,3 +228,46 @@ def test_draw_counts_and_ray_counts(oracle):
             assert d in (0, 1 + 4 * b, 4 * b) or (b == 0 and d == 0)
             seen.add(r)
     assert len(seen) >= 4  # paths of several lengths were exercised
+
+
+# ---- preview shader (SIMPLEDRAW, Raytracer.cpp:147-160) and progressive blocks (:233-248) ----
+def test_preview_shader_known_answers(oracle):
+    S = oracle.OBJ_SPHERE
+    # head-on hit of a matte sphere (k = 0): colour = base + emissive, no env term; alpha 0
+    objs = [dict(type=S, position=(0, 0, 5), radius=1, base=(.2, .4, .6), emissive=(.1, 0, 0), specular_amount=0.0)]
+    arr, n = oracle.make_objects(objs)
+    kw = dict(spp=1, bounces=8, seed=0, preview=True)
+    fb, acc, rays = oracle.render(arr, n, oracle.default_environment(), oracle.default_camera(), 64, 64, **kw)
+    f = np.float32
+    assert list(acc[32, 32]) == [f(.2) * f(1) + f(.1), f(.4), f(.6), 0]
+    assert rays == 64 * 64  # one ray per pixel, no bounces
+    # selected: fresnel = smoothstep(0, .5, 1 - dot(-n, d)); head-on gives 0 -> unchanged; at the
+    # silhouette it saturates to 1 -> Color(3, 3, 0)
+    fb2, acc2, _ = oracle.render(arr, n, oracle.default_environment(), oracle.default_camera(), 64, 64, selected=0, **kw)
+    assert list(acc2[32, 32]) == list(acc[32, 32])
+    ys, xs = np.nonzero((acc2[..., 0] == 3) & (acc2[..., 1] == 3) & (acc2[..., 2] == 0))
+    assert len(xs) > 10 and not np.array_equal(acc2, acc)
+    # a mirror (k = s = 1, base 0) looking straight up reflects env(reflect(d, n))
+    objs = [dict(type=S, position=(0, -101, 5), radius=100, base=(0, 0, 0), specular_amount=1.0, smoothness=1.0)]
+    arr, n = oracle.make_objects(objs)
+    _, acc3, _ = oracle.render(arr, n, oracle.default_environment(), oracle.default_camera(), 64, 64, **kw)
+    assert (acc3[5, 32, :3] > 0.5).all()  # floor pixel shows sky
+
+
+def test_block_anchor_formula_equals_the_literal_loop_nest(oracle):
+    """steps x steps replication: the per-pixel anchor formula used by the oracle's normal
+    walk (and by the GPU kernel) equals renderArea's literal loops over 16 column stripes."""
+    from conftest import scene_path
+    arr, n = oracle.make_objects(oracle.load_scene_json_py(scene_path("Scene2")))
+    env, cam = oracle.default_environment(), oracle.default_camera()
+    for w, h, steps in [(160, 90, 2), (131, 67, 4), (97, 50, 8)]:
+        div = w // 16 + 1  # Raytracer.cpp:330
+        for preview in (True, False):
+            kw = dict(spp=1, bounces=3, seed=1, steps=steps, stripe_width=div, preview=preview)
+            lit = oracle.render(arr, n, env, cam, w, h, threads=16, split=oracle.SPLIT_REF_COLS, **kw)
+            fm = oracle.render(arr, n, env, cam, w, h, threads=3, split=oracle.SPLIT_ROWS, **kw)
+            assert np.array_equal(lit[0], fm[0]) and np.array_equal(lit[1], fm[1])
+            if not preview:
+                assert lit[2] < fm[2]  # the literal walk traces one ray per block, the formula one per pixel
+            # blocks really replicate: pixel (1,1) equals its anchor (0,0) when steps > 1
+            assert np.array_equal(fm[1][0, 0], fm[1][1, 1])
