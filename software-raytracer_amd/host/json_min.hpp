@@ -28,6 +28,122 @@ class JsonError : public std::runtime_error {
     explicit JsonError(const std::string& m) : std::runtime_error(m) {}
 };
 
+
+// ---- Grisu2 (Loitsch, PLDI 2010): shortest-or-nearly-shortest digits of a double --------
+// The reference writes scenes with nlohmann/json 3.11.2, whose number writer is Grisu2 with
+// alpha = -60, gamma = -32 and cached powers 10^k, k = -300 + 8j.  To reproduce its files byte
+// for byte we need the same digit CHOICE where several 17-digit strings round-trip, so the
+// algorithm is implemented here from the paper (not a correctly-rounding printer).
+namespace grisu {
+
+struct DiyFp {
+    uint64_t f;
+    int e;
+};
+struct CachedPower {
+    uint64_t f;
+    int e;
+    int k;
+};
+static const CachedPower kPowers[] = {
+#include "grisu_powers.inc"
+};
+
+inline DiyFp mul(DiyFp x, DiyFp y) {  // upper 64 bits of the 128-bit product, rounded
+    const uint64_t u_lo = x.f & 0xFFFFFFFFu, u_hi = x.f >> 32, v_lo = y.f & 0xFFFFFFFFu, v_hi = y.f >> 32;
+    const uint64_t p0 = u_lo * v_lo, p1 = u_lo * v_hi, p2 = u_hi * v_lo, p3 = u_hi * v_hi;
+    uint64_t q = (p0 >> 32) + (p1 & 0xFFFFFFFFu) + (p2 & 0xFFFFFFFFu);
+    q += uint64_t{1} << 31;
+    return {p3 + (p2 >> 32) + (p1 >> 32) + (q >> 32), x.e + y.e + 64};
+}
+inline DiyFp normalize(DiyFp x) {
+    while ((x.f >> 63) == 0) {
+        x.f <<= 1;
+        x.e--;
+    }
+    return x;
+}
+inline DiyFp normalize_to(DiyFp x, int e) { return {x.f << (x.e - e), e}; }
+
+// digits of v (> 0, finite) into buf; value = digits * 10^decimal_exponent
+inline void shortest(double value, char* buf, int& len, int& decimal_exponent) {
+    uint64_t bits;
+    std::memcpy(&bits, &value, 8);
+    const uint64_t F = bits & ((uint64_t{1} << 52) - 1), E = bits >> 52;
+    const int kBias = 1075, kMinExp = 1 - kBias;
+    const uint64_t hidden = uint64_t{1} << 52;
+    const DiyFp v = E == 0 ? DiyFp{F, kMinExp} : DiyFp{F + hidden, (int)E - kBias};
+    // boundaries m- and m+ (half-way to the neighbouring doubles)
+    const bool lower_closer = F == 0 && E > 1;
+    const DiyFp m_plus{2 * v.f + 1, v.e - 1};
+    const DiyFp m_minus = lower_closer ? DiyFp{4 * v.f - 1, v.e - 2} : DiyFp{2 * v.f - 1, v.e - 1};
+    const DiyFp w_plus = normalize(m_plus);
+    const DiyFp w_minus = normalize_to(m_minus, w_plus.e);
+    const DiyFp w_v = normalize(v);
+    // cached power c = 10^-k with alpha <= e_c + e + 64 <= gamma  (alpha = -60, gamma = -32)
+    const int e = w_plus.e;
+    const int f = -60 - e - 1;
+    const int k = (f * 78913) / (1 << 18) + (f > 0 ? 1 : 0);
+    const int index = (300 + k + 7) / 8;
+    const CachedPower cp = kPowers[index];
+    const DiyFp c{cp.f, cp.e};
+    const DiyFp w = mul(w_v, c), wm = mul(w_minus, c), wp = mul(w_plus, c);
+    const DiyFp M_minus{wm.f + 1, wm.e}, M_plus{wp.f - 1, wp.e};  // safe interval
+    decimal_exponent = -cp.k;
+    // digit generation
+    uint64_t delta = M_plus.f - M_minus.f, dist = M_plus.f - w.f;
+    const DiyFp one{uint64_t{1} << -M_plus.e, M_plus.e};
+    uint32_t p1 = (uint32_t)(M_plus.f >> -one.e);
+    uint64_t p2 = M_plus.f & (one.f - 1);
+    uint32_t pow10 = 1;
+    int n = 1;
+    {
+        static const uint32_t tens[] = {1000000000u, 100000000u, 10000000u, 1000000u, 100000u, 10000u, 1000u, 100u, 10u, 1u};
+        for (int i = 0; i < 10; ++i)
+            if (p1 >= tens[i]) {
+                pow10 = tens[i];
+                n = 10 - i;
+                break;
+            }
+    }
+    len = 0;
+    auto round_weed = [&](uint64_t rest, uint64_t ten_k) {
+        while (rest < dist && delta - rest >= ten_k && (rest + ten_k < dist || dist - rest > rest + ten_k - dist)) {
+            buf[len - 1]--;
+            rest += ten_k;
+        }
+    };
+    while (n > 0) {
+        const uint32_t d = p1 / pow10, r = p1 % pow10;
+        buf[len++] = (char)('0' + d);
+        p1 = r;
+        n--;
+        const uint64_t rest = (uint64_t{p1} << -one.e) + p2;
+        if (rest <= delta) {
+            decimal_exponent += n;
+            round_weed(rest, uint64_t{pow10} << -one.e);
+            return;
+        }
+        pow10 /= 10;
+    }
+    int m = 0;
+    for (;;) {
+        p2 *= 10;
+        const uint64_t d = p2 >> -one.e, r = p2 & (one.f - 1);
+        buf[len++] = (char)('0' + d);
+        p2 = r;
+        m++;
+        delta *= 10;
+        dist *= 10;
+        if (p2 <= delta) break;
+    }
+    decimal_exponent -= m;
+    round_weed(p2, one.f);
+}
+
+}  // namespace grisu
+
+
 class Json {
    public:
     enum class Kind { Null, Bool, Int, Uint, Float, String, Array, Object };
@@ -154,22 +270,15 @@ class Json {
         return out;
     }
 
-    // shortest round-trip decimal of a double in nlohmann's layout
+    // Grisu2 digits of a double in nlohmann's layout (min_exp = -4, max_exp = 15)
     static std::string format_double(double v) {
         if (!std::isfinite(v)) return "null";  // nlohmann dumps NaN/inf as null
         if (v == 0) return std::signbit(v) ? "-0.0" : "0.0";
         char digits[32];
-        auto r = std::to_chars(digits, digits + sizeof digits, std::fabs(v), std::chars_format::scientific);
-        // digits = d[.ddd]e[+-]XX  -> mantissa digits + decimal exponent
-        std::string sci(digits, r.ptr);
-        size_t epos = sci.find('e');
-        std::string mant = sci.substr(0, epos);
-        int exp10 = std::atoi(sci.c_str() + epos + 1);
-        std::string ds;
-        for (char c : mant)
-            if (c != '.') ds.push_back(c);
-        const int k = (int)ds.size();  // number of significant digits
-        const int n = exp10 + 1;       // position of the decimal point relative to the digits
+        int k = 0, dexp = 0;
+        grisu::shortest(std::fabs(v), digits, k, dexp);
+        std::string ds(digits, (size_t)k);
+        const int n = k + dexp;  // position of the decimal point relative to the digits
         std::string out = v < 0 ? "-" : "";
         const int min_exp = -4, max_exp = 15;
         if (k <= n && n <= max_exp) {  // digits[000].0
