@@ -550,6 +550,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         // handed out, [0, own_done) folded.  A slot may run `depth` samples ahead of its own
         // fold point (ring capacity); slots do not wait for each other.
         uint32_t own_next = own_done;
+        int rot = 0;  // wave-uniform rotation of the slot priority
 
         while (true) {
             // ---- fold finished samples, in order, into the owners' running means
@@ -576,7 +577,12 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 const unsigned long long canm = __builtin_amdgcn_ballot_w64(can);
                 if (freem == 0ull || canm == 0ull) break;
                 const int nfree = __builtin_popcountll(freem);
-                const int crank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(canm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)canm, 0u));
+                // slot priority rotates every round so that all slots advance at the same pace
+                // (a fixed order would starve the high slots and leave them for a thin tail)
+                rot = (rot + 23) & 63;
+                const unsigned long long canr = rot ? ((canm >> rot) | (canm << (64 - rot))) : canm;
+                const int lr = (lane - rot) & 63;
+                const int crank = __builtin_popcountll(canr & ((1ull << lr) - 1ull));
                 const int frank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(freem >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)freem, 0u));
                 unsigned* match = reinterpret_cast<unsigned*>(S.work);  // [64] of (sample << 6 | slot)
                 if (can && crank < nfree) {
