@@ -78,6 +78,17 @@ constexpr int WG_SCRATCH_BYTES = WAVE_SCRATCH_BYTES * WG_TILES_X * WG_TILES_Y;
 
 __device__ __forceinline__ float clamp0(float v) { return v < 0 ? 0.0f : v; }  // Common.hpp:254-257
 
+// (float)rand() / RAND_MAX (Raytracer.cpp:93-95,165,182) for r in [0, 32767]: the correctly rounded
+// quotient via one Newton correction (q0 = r*y, e = fma(-q0, b, r), q = fma(e, y, q0)) instead of
+// the generic IEEE divide expansion.  Equal to r / 32767.0f for ALL 32768 inputs — checked
+// exhaustively on the CPU (tests/test_defs.py) — so the bits are the reference's.
+__device__ __forceinline__ float rand_unit(uint32_t r) {
+    const float b = 32767.0f, y = 0x1.0002p-15f;  // y = RN(1/b)
+    const float a = (float)r;
+    const float q0 = a * y;
+    return __builtin_fmaf(__builtin_fmaf(-q0, b, a), y, q0);
+}
+
 struct V3 {
     float x, y, z;
 };
@@ -183,18 +194,27 @@ __device__ __forceinline__ void hit_unkey(unsigned long long k, float& t, int& p
 __device__ __forceinline__ Hit closest_hit(const Lds& S, V3 o, V3 d, bool active) {
     float best = __builtin_inff();
     int bp = -1;
-    // exact sphere test of ray (ro, rd) against sphere s; updates (tb, pb) with the tie rule
-    auto test = [&](const float4 s, int p, V3 ro, V3 rd, bool on, float& tb, int& pb) {
+    // exact sphere test of ray (ro, rd) against four spheres; updates (tb, pb) with the tie rule.
+    // Part 1 (always): the cheap candidate test d2 <= r*r.  Part 2 (sqrt, compare) runs under
+    // ONE wave-uniform branch per group and one more per sphere, so a group nobody can hit
+    // costs a single branch.
+    struct Cand {
+        float tc, x;  // tc and r*r - d2
+        bool c;
+    };
+    auto part1 = [&](const float4 s, V3 ro, V3 rd, bool on) {
         // Sphere::line_sphere_intersection (Object.hpp:104-141)
         float Lx = s.x - ro.x, Ly = s.y - ro.y, Lz = s.z - ro.z;                    // :115
         float tc = fabsf((Lx * rd.x + Ly * rd.y) + Lz * rd.z);                      // :118-119
         float qx = rd.x * tc + ro.x, qy = rd.y * tc + ro.y, qz = rd.z * tc + ro.z;  // :121
         float ex = qx - s.x, ey = qy - s.y, ez = qz - s.z;                          // :124
         float d2 = (ex * ex + ey * ey) + ez * ez;                                   // :125
-        bool cand = on && !(d2 > s.w);                                              // :127
-        if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {                            // wave-uniform skip
-            float t1 = tc - sqrtf(s.w - d2);                                        // :131-133
-            if (cand) {
+        return Cand{tc, s.w - d2, on && !(d2 > s.w)};                               // :127
+    };
+    auto part2 = [&](const Cand& k, int p, float& tb, int& pb) {
+        if (__builtin_amdgcn_ballot_w64(k.c) != 0ull) {
+            float t1 = k.tc - sqrtf(k.x);  // :131-133
+            if (k.c) {
                 if (t1 < tb) {  // Raytracer.cpp:130-132
                     tb = t1;
                     pb = p;
@@ -204,13 +224,20 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, V3 o, V3 d, bool active
             }
         }
     };
+    auto test4 = [&](const float4 s0, const float4 s1, const float4 s2, const float4 s3, int p, V3 ro, V3 rd, bool on, float& tb,
+                     int& pb) {
+        const Cand k0 = part1(s0, ro, rd, on), k1 = part1(s1, ro, rd, on), k2 = part1(s2, ro, rd, on), k3 = part1(s3, ro, rd, on);
+        if (__builtin_amdgcn_ballot_w64(k0.c | k1.c | k2.c | k3.c) != 0ull) {
+            part2(k0, p, tb, pb);
+            part2(k1, p + 1, tb, pb);
+            part2(k2, p + 2, tb, pb);
+            part2(k3, p + 3, tb, pb);
+        }
+    };
     // ---- 1. uniform spheres: broadcast ds_read_b128, 4 per trip
     for (int j = 0; j < S.nu4; j += 4) {
         const float4 s0 = S.v[j], s1 = S.v[j + 1], s2 = S.v[j + 2], s3 = S.v[j + 3];
-        test(s0, j, o, d, active, best, bp);
-        test(s1, j + 1, o, d, active, best, bp);
-        test(s2, j + 2, o, d, active, best, bp);
-        test(s3, j + 3, o, d, active, best, bp);
+        test4(s0, s1, s2, s3, j, o, d, active, best, bp);
     }
     // ---- 2. clustered spheres
     if (S.nc > 0) {
@@ -267,10 +294,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, V3 o, V3 d, bool active
                     for (int i = 0; i < K4; ++i) {
                         const int p = S.nu4 + (k * K4 + i) * 4;  // per-lane LDS gather
                         const float4 s0 = S.v[p], s1 = S.v[p + 1], s2 = S.v[p + 2], s3 = S.v[p + 3];
-                        test(s0, p, ro, rd, on, tb, pb);
-                        test(s1, p + 1, ro, rd, on, tb, pb);
-                        test(s2, p + 2, ro, rd, on, tb, pb);
-                        test(s3, p + 3, ro, rd, on, tb, pb);
+                        test4(s0, s1, s2, s3, p, ro, rd, on, tb, pb);
                     }
                     if (pb >= 0) atomicMin(&S.res[src], hit_key(tb, S.order(pb), pb));
                 }
@@ -285,20 +309,14 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, V3 o, V3 d, bool active
                     for (int i = 0; i < K4; ++i) {
                         const int p = S.nu4 + (k * K4 + i) * 4;
                         const float4 s0 = S.v[p], s1 = S.v[p + 1], s2 = S.v[p + 2], s3 = S.v[p + 3];
-                        test(s0, p, o, d, on, best, bp);
-                        test(s1, p + 1, o, d, on, best, bp);
-                        test(s2, p + 2, o, d, on, best, bp);
-                        test(s3, p + 3, o, d, on, best, bp);
+                        test4(s0, s1, s2, s3, p, o, d, on, best, bp);
                     }
                 }
             }
         } else {  // some lane's direction is not unit length (degenerate lerp): brute force
             for (int j = S.nu4; j < S.nsT; j += 4) {
                 const float4 s0 = S.v[j], s1 = S.v[j + 1], s2 = S.v[j + 2], s3 = S.v[j + 3];
-                test(s0, j, o, d, active, best, bp);
-                test(s1, j + 1, o, d, active, best, bp);
-                test(s2, j + 2, o, d, active, best, bp);
-                test(s3, j + 3, o, d, active, best, bp);
+                test4(s0, s1, s2, s3, j, o, d, active, best, bp);
             }
         }
     }
@@ -601,7 +619,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                     uint32_t rr = srt_mix32(rng) >> 17;
                     rng += 0x9E3779B9U;
                     float4 m0 = S.mat(prim0, 0), m1 = S.mat(prim0, 1);
-                    spec = (m0.y >= ((float)rr / (float)SRT_RAND_MAX)) ? 1.0f : 0.0f;  // :165
+                    spec = (m0.y >= rand_unit(rr)) ? 1.0f : 0.0f;  // :165
                     L = RGB{clamp0(m1.y), clamp0(m1.z), clamp0(m1.w)};                 // :162
                     T = RGB{clamp0(m0.z), clamp0(m0.w), clamp0(m1.x)};                 // :163
                     sray = v3(r[0], r[1], r[2]);                                       // :164
@@ -629,8 +647,8 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 uint32_t r1 = srt_mix32(rng + 0x9E3779B9U) >> 17;
                 uint32_t r2 = srt_mix32(rng + 2u * 0x9E3779B9U) >> 17;
                 rng += 3u * 0x9E3779B9U;
-                V3 sr = v3(((float)r0 / (float)SRT_RAND_MAX - 0.5f) * 2, ((float)r1 / (float)SRT_RAND_MAX - 0.5f) * 2,
-                           ((float)r2 / (float)SRT_RAND_MAX - 0.5f) * 2);
+                V3 sr = v3((rand_unit(r0) - 0.5f) * 2, (rand_unit(r1) - 0.5f) * 2,
+                           (rand_unit(r2) - 0.5f) * 2);
                 sr = normalized(sr);
                 if (dot3(sr, hn) < 0) sr = v3(sr.x * -1, sr.y * -1, sr.z * -1);
                 // float3::Lerp(sray, reflectedRay, Smoothness * specularProb)  (:175)
@@ -653,7 +671,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                     float4 m0 = S.mat(h.prim, 0), m1 = S.mat(h.prim, 1), m2 = S.mat(h.prim, 2);
                     uint32_t r = srt_mix32(rng) >> 17;
                     rng += 0x9E3779B9U;
-                    spec = (m0.y >= ((float)r / (float)SRT_RAND_MAX)) ? 1.0f : 0.0f;  // :182
+                    spec = (m0.y >= rand_unit(r)) ? 1.0f : 0.0f;  // :182
                     RGB Em{clamp0(m1.y), clamp0(m1.z), clamp0(m1.w)};
                     L = RGB{clamp0(L.r + clamp0(Em.r * T.r)), clamp0(L.g + clamp0(Em.g * T.g)), clamp0(L.b + clamp0(Em.b * T.b))};  // :183
                     RGB Bc{clamp0(m0.z), clamp0(m0.w), clamp0(m1.x)}, Sc{clamp0(m2.x), clamp0(m2.y), clamp0(m2.z)};

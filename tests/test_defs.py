@@ -87,3 +87,29 @@ def test_oracle_powf_is_the_shared_one(oracle):
     for x in xs:
         a = L.srt_oracle_powf_shared(float(x), 0.1)
         assert abs(a - float(x) ** np.float32(0.1)) <= 2e-7 * max(a, 1e-30) + 1e-30
+
+
+def test_fast_division_by_rand_max_is_exact(tmp_path):
+    """The kernel replaces (float)r / 32767.0f by q0 = r*y; q = fma(fma(-q0, b, r), y, q0).
+    Exhaustive over the whole input range: identical bits."""
+    src = r'''
+#include <stdio.h>
+#include <math.h>
+int main(void){ const float b=32767.0f, y=0x1.0002p-15f; long bad=0; if (y != 1.0f/b) bad=-1;
+ for(int r=0;r<=32767;r++){ float a=(float)r, q0=a*y, q=fmaf(fmaf(-q0,b,a),y,q0); if(q!=a/b) bad++; }
+ printf("%ld\n",bad); return 0; }
+'''
+    (tmp_path / "d.c").write_text(src)
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", str(tmp_path / "d.c"), "-o", str(tmp_path / "d"), "-lm"])
+    assert subprocess.check_output([str(tmp_path / "d")]).decode().strip() == "0"
+
+
+def test_accumulate_weight_float_divide_equals_double_divide(tmp_path):
+    """(float)(1.0 / f) == 1.0f / (float)f for every f <= 2^24 (kernel uses the float divide there)."""
+    src = r'''
+#include <stdio.h>
+int main(void){ long bad=0; for(int f=1; f<=(1<<24); f++){ float a=(float)(1.0/f), b=1.0f/(float)f; if(a!=b) bad++; } printf("%ld\n",bad); return 0; }
+'''
+    (tmp_path / "w.c").write_text(src)
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", str(tmp_path / "w.c"), "-o", str(tmp_path / "w")])
+    assert subprocess.check_output([str(tmp_path / "w")]).decode().strip() == "0"
