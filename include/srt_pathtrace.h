@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SRT_ABI_VERSION 2
+#define SRT_ABI_VERSION 3
 
 typedef enum srt_status {
     SRT_OK = 0,
@@ -56,7 +56,9 @@ typedef enum srt_status {
 typedef enum srt_object_type {
     SRT_OBJ_NONE = 0,    /* inert Object: occupies a list slot, never hit (Object.hpp:21-23) */
     SRT_OBJ_SPHERE = 1,  /* Sphere (Object.hpp:86-168): uses position + radius          */
-    SRT_OBJ_BOX = 2      /* Box    (Object.hpp:170-234): axis-aligned, half_size = Box::size */
+    SRT_OBJ_BOX = 2,     /* Box    (Object.hpp:170-234): axis-aligned, half_size = Box::size */
+    SRT_OBJ_MESH = 3     /* EXTENSION (not in the reference, which has no triangle primitive):
+                            an indexed triangle mesh, see srt_mesh / srt_set_meshes          */
 } srt_object_type;
 
 /* Material (Raytracer/Common.hpp:293-319), 11 floats. Colours are the r,g,b of the
@@ -77,7 +79,21 @@ typedef struct srt_object {
     float radius;        /* Sphere::radius (transform.scale is NOT used by the intersector) */
     float half_size[3];  /* Box::size, half extents */
     srt_material material;
+    int32_t mesh;        /* SRT_OBJ_MESH: index into the array given to srt_set_meshes; else ignored */
 } srt_object;
+
+/* EXTENSION — triangle meshes (BASELINE.json configs 4-5).  The reference defines no triangle
+ * arithmetic, so this project does: world vertex = vertex + object position
+ * (binary32 add); Moller-Trumbore in binary32 without FMA in a fixed operation order; a hit is
+ * valid for 0.01 <= t <= 10000 (the Box bounds, Object.hpp:226); the normal is the unit geometric
+ * normal turned against the ray.  Among equal distances the earlier object in ObjectsToRender
+ * wins, then the lower triangle index.  Vertices: 3 floats each; indices: 3 uint32 per triangle. */
+typedef struct srt_mesh {
+    const float* vertices;
+    size_t vertex_count;
+    const uint32_t* indices;
+    size_t triangle_count;
+} srt_mesh;
 
 /* Environment globals (Raytracer.cpp:55-59). sun_direction is the already normalised
  * vector (the reference normalises once at start-up, :264). */
@@ -148,6 +164,8 @@ const char* srt_last_error(const srt_context* ctx);
 /* ---- state the worker reads ---------------------------------------------------- */
 /* Replaces ObjectsToRender (Raytracer.cpp:61,293). Copies; count may be 0. */
 int srt_set_scene(srt_context* ctx, const srt_object* objects, size_t count);
+/* EXTENSION: mesh geometry referenced by SRT_OBJ_MESH objects.  Call BEFORE srt_set_scene; copies. */
+int srt_set_meshes(srt_context* ctx, const srt_mesh* meshes, size_t count);
 /* Replaces SunDirection/SkyColor/HorizonColor/GroundColor/SunColor (:55-59). */
 int srt_set_environment(srt_context* ctx, const srt_environment* env);
 /* Fills env with the reference's start-up values, computed the way :55-59,264 do. */

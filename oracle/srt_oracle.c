@@ -215,12 +215,72 @@ static rayhit box_raytrace(const srt_object* o, f3 rayOrigin, f3 rayDir) {
     return ret;
 }
 
+/* ------------------------------------------------------------------------------------
+ * EXTENSION — triangle meshes.  NOT a restatement: the reference has no triangle primitive
+ * (Object.hpp defines Sphere and Box only).  This is the project's own definition
+ * (include/srt_pathtrace.h), written in the reference's style: binary32, no FMA,
+ * fixed association, float3 value semantics.
+ * ---------------------------------------------------------------------------------- */
+static f3 f3_cross(f3 a, f3 b) {
+    return f3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+/* Moller-Trumbore for the triangle (v0, v0+e1, v0+e2) */
+static rayhit triangle_raytrace(f3 v0, f3 e1, f3 e2, f3 rayOrigin, f3 rayDir) {
+    rayhit h = rayhit_default();
+    f3 pvec = f3_cross(rayDir, e2);
+    float det = f3_dot(e1, pvec);
+    if (fabsf(det) < 1e-12f) return h; /* ray parallel to the plane (also false for NaN) */
+    if (!(fabsf(det) >= 1e-12f)) return h;
+    float inv = 1.0f / det;
+    f3 tvec = f3_sub(rayOrigin, v0);
+    float u = f3_dot(tvec, pvec) * inv;
+    if (!(u >= 0.0f && u <= 1.0f)) return h;
+    f3 qvec = f3_cross(tvec, e1);
+    float v = f3_dot(rayDir, qvec) * inv;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return h;
+    float t = f3_dot(e2, qvec) * inv;
+    if (!(t >= (float)0.01 && t <= 10000.0f)) return h; /* the Box distance bounds, Object.hpp:226 */
+    f3 n = f3_normalized(f3_cross(e1, e2));
+    if (f3_dot(n, rayDir) > 0) n = f3_muls(n, -1); /* face the ray */
+    h.valid = 1;
+    h.distance = t;
+    h.point = f3_add(rayOrigin, f3_muls(rayDir, t));
+    h.normal = n;
+    return h;
+}
+
+/* a mesh object: closest valid triangle; strict '<' keeps the lower triangle index on ties */
+static rayhit mesh_raytrace(const srt_object* o, const srt_mesh* meshes, size_t mesh_count, f3 origin, f3 dir) {
+    rayhit best = rayhit_default();
+    if (!meshes || o->mesh < 0 || (size_t)o->mesh >= mesh_count) return best;
+    const srt_mesh* m = &meshes[o->mesh];
+    f3 pos = f3_make(o->position[0], o->position[1], o->position[2]);
+    float shortest = INFINITY;
+    for (size_t k = 0; k < m->triangle_count; ++k) {
+        const uint32_t* ix = m->indices + 3 * k;
+        if (ix[0] >= m->vertex_count || ix[1] >= m->vertex_count || ix[2] >= m->vertex_count) continue;
+        const float *a = m->vertices + 3 * (size_t)ix[0], *b = m->vertices + 3 * (size_t)ix[1], *c = m->vertices + 3 * (size_t)ix[2];
+        f3 v0 = f3_add(f3_make(a[0], a[1], a[2]), pos); /* world vertex = vertex + position */
+        f3 v1 = f3_add(f3_make(b[0], b[1], b[2]), pos);
+        f3 v2 = f3_add(f3_make(c[0], c[1], c[2]), pos);
+        rayhit h = triangle_raytrace(v0, f3_sub(v1, v0), f3_sub(v2, v0), origin, dir);
+        if (h.valid && h.distance < shortest) {
+            shortest = h.distance;
+            best = h;
+        }
+    }
+    return best;
+}
+
 /* virtual Object::Raytrace dispatch (Object.hpp:21-23,153,224) */
-static rayhit object_raytrace(const srt_object* o, f3 origin, f3 dir) {
+static rayhit object_raytrace_m(const srt_object* o, const srt_mesh* meshes, size_t mesh_count, f3 origin, f3 dir) {
     if (o->type == SRT_OBJ_SPHERE) return sphere_raytrace(o, origin, dir);
     if (o->type == SRT_OBJ_BOX) return box_raytrace(o, origin, dir);
+    if (o->type == SRT_OBJ_MESH) return mesh_raytrace(o, meshes, mesh_count, origin, dir);
     return rayhit_default();
 }
+static rayhit object_raytrace(const srt_object* o, f3 origin, f3 dir) { return object_raytrace_m(o, NULL, 0, origin, dir); }
 
 /* ------------------------------------------------------------------------------------
  * Render context: the globals of Raytracer.cpp:30-35,46-48,55-61
@@ -228,6 +288,8 @@ static rayhit object_raytrace(const srt_object* o, f3 origin, f3 dir) {
 typedef struct octx {
     const srt_object* objects;
     size_t count;
+    const srt_mesh* meshes;
+    size_t mesh_count;
     const srt_environment* env;
     int32_t width, height; /* SCREEN_WIDTH / SCREEN_HEIGHT :26-27 */
     int32_t fov;           /* FOV :31 */
@@ -259,7 +321,7 @@ static rayhitobject get_closest_object(octx* c, f3 rayOrigin, f3 rayDirection) {
     float shortestDistance = INFINITY; /* :126 */
     c->rays++;
     for (size_t i = 0; i < c->count; i++) { /* :127 */
-        rayhit hitResults = object_raytrace(&c->objects[i], rayOrigin, rayDirection);
+        rayhit hitResults = object_raytrace_m(&c->objects[i], c->meshes, c->mesh_count, rayOrigin, rayDirection);
         if (hitResults.valid) {                            /* :130 */
             if (hitResults.distance < shortestDistance) {  /* :132 strict: first wins ties */
                 returnResults.objectReference = (int)i;
@@ -462,6 +524,8 @@ static void* worker_main(void* arg) {
     memset(&c, 0, sizeof c);
     c.objects = job->objects;
     c.count = job->object_count;
+    c.meshes = job->meshes;
+    c.mesh_count = job->mesh_count;
     c.env = job->env;
     c.width = job->width;
     c.height = job->height;
@@ -592,6 +656,17 @@ static void put3(float o[3], f3 v) {
 int srt_oracle_intersect(const srt_object* obj, const float origin[3], const float dir[3],
                          float out_normal[3], float out_point[3], float* out_distance) {
     rayhit h = object_raytrace(obj, f3_make(origin[0], origin[1], origin[2]), f3_make(dir[0], dir[1], dir[2]));
+    put3(out_normal, h.normal);
+    put3(out_point, h.point);
+    *out_distance = h.distance;
+    return h.valid;
+}
+
+int srt_oracle_triangle(const float v0[3], const float v1[3], const float v2[3], const float origin[3],
+                        const float dir[3], float out_normal[3], float out_point[3], float* out_distance) {
+    f3 a = f3_make(v0[0], v0[1], v0[2]), b = f3_make(v1[0], v1[1], v1[2]), c = f3_make(v2[0], v2[1], v2[2]);
+    rayhit h = triangle_raytrace(a, f3_sub(b, a), f3_sub(c, a), f3_make(origin[0], origin[1], origin[2]),
+                                 f3_make(dir[0], dir[1], dir[2]));
     put3(out_normal, h.normal);
     put3(out_point, h.point);
     *out_distance = h.distance;

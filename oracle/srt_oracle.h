@@ -33,6 +33,8 @@ extern "C" {
 typedef struct srt_oracle_job {
     const srt_object* objects;
     size_t object_count;
+    const srt_mesh* meshes;   /* EXTENSION (srt_pathtrace.h): geometry of SRT_OBJ_MESH objects, may be NULL */
+    size_t mesh_count;
     const srt_environment* env;
     const srt_camera* camera;
     int32_t width, height;
@@ -55,6 +57,10 @@ void srt_oracle_ray_direction(const srt_camera* cam, int32_t width, int32_t heig
 /* Object::Raytrace for one object (Object.hpp:153-167 / 224-233): returns valid flag */
 int srt_oracle_intersect(const srt_object* obj, const float origin[3], const float dir[3],
                          float out_normal[3], float out_point[3], float* out_distance);
+/* EXTENSION: this project's triangle test for one triangle given by its three
+ * WORLD vertices; returns valid flag */
+int srt_oracle_triangle(const float v0[3], const float v1[3], const float v2[3], const float origin[3],
+                        const float dir[3], float out_normal[3], float out_point[3], float* out_distance);
 /* GetClosestObject (Raytracer.cpp:123-140): returns object index or -1 */
 int srt_oracle_closest(const srt_object* objects, size_t count, const float origin[3],
                        const float dir[3], float out_normal[3], float out_point[3],

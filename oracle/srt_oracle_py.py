@@ -25,7 +25,7 @@ RENDER_RESET = 1
 RENDER_COUNT_RAYS = 2
 RENDER_PREVIEW = 4
 
-OBJ_NONE, OBJ_SPHERE, OBJ_BOX = 0, 1, 2
+OBJ_NONE, OBJ_SPHERE, OBJ_BOX, OBJ_MESH = 0, 1, 2, 3
 
 
 class Material(C.Structure):
@@ -45,6 +45,16 @@ class Object(C.Structure):
         ("radius", C.c_float),
         ("half_size", C.c_float * 3),
         ("material", Material),
+        ("mesh", C.c_int32),
+    ]
+
+
+class Mesh(C.Structure):
+    _fields_ = [
+        ("vertices", C.POINTER(C.c_float)),
+        ("vertex_count", C.c_size_t),
+        ("indices", C.POINTER(C.c_uint32)),
+        ("triangle_count", C.c_size_t),
     ]
 
 
@@ -87,6 +97,8 @@ class Job(C.Structure):
     _fields_ = [
         ("objects", C.POINTER(Object)),
         ("object_count", C.c_size_t),
+        ("meshes", C.POINTER(Mesh)),
+        ("mesh_count", C.c_size_t),
         ("env", C.POINTER(Environment)),
         ("camera", C.POINTER(Camera)),
         ("width", C.c_int32),
@@ -177,12 +189,57 @@ def make_objects(objs):
         a.position = f3(o.get("position", (0, 0, 0)))
         a.radius = float(o.get("radius", 0.0))
         a.half_size = f3(o.get("half_size", (0, 0, 0)))
+        a.mesh = int(o.get("mesh", -1))
         a.material.smoothness = float(o.get("smoothness", 0.5))
         a.material.specular_amount = float(o.get("specular_amount", 0.0))
         a.material.base_color = f3(o.get("base", (1, 1, 1)))
         a.material.emissive_color = f3(o.get("emissive", (0, 0, 0)))
         a.material.specular_color = f3(o.get("specular", (1, 1, 1)))
     return arr, len(objs)
+
+
+def make_meshes(meshes):
+    """list of (vertices float32 [n,3], indices uint32 [m,3]) -> (ctypes Mesh array, count, keepalive)."""
+    arr = (Mesh * max(1, len(meshes)))()
+    keep = []
+    for i, (v, ix) in enumerate(meshes):
+        v = np.ascontiguousarray(v, dtype=np.float32).reshape(-1, 3)
+        ix = np.ascontiguousarray(ix, dtype=np.uint32).reshape(-1, 3)
+        keep += [v, ix]
+        arr[i].vertices = v.ctypes.data_as(C.POINTER(C.c_float))
+        arr[i].vertex_count = v.shape[0]
+        arr[i].indices = ix.ctypes.data_as(C.POINTER(C.c_uint32))
+        arr[i].triangle_count = ix.shape[0]
+    return arr, len(meshes), keep
+
+
+def uv_sphere(radius, stacks, slices):
+    """Deterministic lat-long tessellation used by BASELINE config 4: `stacks` bands
+    of latitude, `slices` of longitude; the pole bands are fans -> 2*slices*(stacks-1) triangles.
+    float32 vertices, outward (counter-clockwise) winding.  Must match host/mesh.cpp."""
+    vs = [(0.0, radius, 0.0)]
+    import math
+    for i in range(1, stacks):
+        phi = math.pi * i / stacks
+        y, r = radius * math.cos(phi), radius * math.sin(phi)
+        for j in range(slices):
+            th = 2.0 * math.pi * j / slices
+            vs.append((r * math.cos(th), y, r * math.sin(th)))
+    vs.append((0.0, -radius, 0.0))
+    V = np.array(vs, dtype=np.float64).astype(np.float32)
+    tri = []
+    ring = lambda i, j: 1 + (i - 1) * slices + (j % slices)
+    south = len(vs) - 1
+    for j in range(slices):
+        tri.append((0, ring(1, j + 1), ring(1, j)))
+    for i in range(1, stacks - 1):
+        for j in range(slices):
+            a, b, c, d = ring(i, j), ring(i, j + 1), ring(i + 1, j), ring(i + 1, j + 1)
+            tri.append((a, b, d))
+            tri.append((a, d, c))
+    for j in range(slices):
+        tri.append((south, ring(stacks - 1, j), ring(stacks - 1, j + 1)))
+    return V, np.array(tri, dtype=np.uint32)
 
 
 def _clamp0(v):
@@ -221,7 +278,7 @@ def load_scene_json_py(path):
 
 def render(objects, count, env, cam, width, height, *, spp=1, bounces=4, seed=0, first_sample=1,
            reset=True, rows=None, accumulator=None, pow_mode=POW_SHARED, threads=None,
-           split=SPLIT_ROWS, preview=False, steps=1, stripe_width=0, selected=-1):
+           split=SPLIT_ROWS, preview=False, steps=1, stripe_width=0, selected=-1, meshes=None):
     """Run the oracle. Returns (framebuffer uint32 [H,W] bottom-up, accumulator float32
     [H,W,4] scene rows, rays)."""
     if threads is None:
@@ -234,6 +291,9 @@ def render(objects, count, env, cam, width, height, *, spp=1, bounces=4, seed=0,
     job = Job()
     job.objects = C.cast(objects, C.POINTER(Object))
     job.object_count = count
+    if meshes is not None:
+        job.meshes = C.cast(meshes[0], C.POINTER(Mesh))
+        job.mesh_count = meshes[1]
     job.env = C.pointer(env)
     job.camera = C.pointer(cam)
     job.width, job.height = width, height

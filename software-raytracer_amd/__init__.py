@@ -24,6 +24,7 @@ from .capi import (  # noqa: F401
     Camera,
     Environment,
     Material,
+    Mesh,
     Object,
     PathTracer,
     RenderParams,

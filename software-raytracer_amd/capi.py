@@ -14,14 +14,14 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_PKG, "libsrt_pathtrace.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_OOM = range(6)
-OBJ_NONE, OBJ_SPHERE, OBJ_BOX = 0, 1, 2
+OBJ_NONE, OBJ_SPHERE, OBJ_BOX, OBJ_MESH = 0, 1, 2, 3
 RENDER_RESET, RENDER_COUNT_RAYS, RENDER_PREVIEW = 1, 2, 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/srt_pathtrace.h declares (tests check the library exports them all)
 EXPORTS = [
     "srt_abi_version", "srt_device_count", "srt_create", "srt_destroy", "srt_last_error",
-    "srt_set_scene", "srt_set_environment", "srt_environment_default", "srt_set_camera",
+    "srt_set_scene", "srt_set_meshes", "srt_set_environment", "srt_environment_default", "srt_set_camera",
     "srt_set_stream", "srt_bind_output", "srt_device_framebuffer", "srt_device_accumulator",
     "srt_render", "srt_wait", "srt_poll", "srt_get_stats", "srt_pick", "srt_read_framebuffer",
     "srt_read_accumulator", "srt_write_accumulator",
@@ -51,6 +51,16 @@ class Object(C.Structure):
         ("radius", C.c_float),
         ("half_size", C.c_float * 3),
         ("material", Material),
+        ("mesh", C.c_int32),
+    ]
+
+
+class Mesh(C.Structure):
+    _fields_ = [
+        ("vertices", C.POINTER(C.c_float)),
+        ("vertex_count", C.c_size_t),
+        ("indices", C.POINTER(C.c_uint32)),
+        ("triangle_count", C.c_size_t),
     ]
 
 
@@ -126,6 +136,7 @@ def load_library():
     L.srt_last_error.argtypes = [ctx]
     L.srt_last_error.restype = C.c_char_p
     L.srt_set_scene.argtypes = [ctx, C.POINTER(Object), C.c_size_t]
+    L.srt_set_meshes.argtypes = [ctx, C.POINTER(Mesh), C.c_size_t]
     L.srt_set_environment.argtypes = [ctx, C.POINTER(Environment)]
     L.srt_environment_default.argtypes = [C.POINTER(Environment)]
     L.srt_set_camera.argtypes = [ctx, C.POINTER(Camera)]
@@ -209,6 +220,11 @@ class PathTracer:
         n = len(objects) if count is None else count
         ptr = C.cast(objects, C.POINTER(Object)) if n else None
         self._ck(self.L.srt_set_scene(self._h, ptr, n))
+
+    def set_meshes(self, meshes, count=None):
+        """EXTENSION: geometry for SRT_OBJ_MESH objects; call before set_scene."""
+        n = len(meshes) if count is None else count
+        self._ck(self.L.srt_set_meshes(self._h, C.cast(meshes, C.POINTER(Mesh)) if n else None, n))
 
     def set_environment(self, env):
         self._ck(self.L.srt_set_environment(self._h, C.byref(env)))

@@ -16,6 +16,7 @@
 
 #include "srt_kernel.hip.h"
 #include "srt_scene_image.h"
+#include "srt_mesh_bvh.h"
 #include "srt_pathtrace.h"
 
 namespace {
@@ -51,6 +52,13 @@ struct srt_context {
     float4* d_acc = nullptr;
     unsigned long long* d_rays = nullptr;
     int* d_pick = nullptr;
+    int last_pick[4] = {0, 0, 0, 0};  // list index, distance bits, primitive id, normal.z bits (debug)
+
+    // EXTENSION: triangle meshes
+    std::vector<srt::HostMesh> meshes;
+    srt::MeshImage mesh_image;
+    float4* d_bvh_nodes = nullptr;
+    float4* d_bvh_tris = nullptr;
 
     srt_environment env;
     HostCamera camera;
@@ -159,7 +167,7 @@ int srt_create(int device, int width, int height, srt_context** out) {
     if ((e = hipMalloc((void**)&ctx->d_fb_own, px * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc framebuffer");
     if ((e = hipMalloc((void**)&ctx->d_acc_own, px * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc accumulator");
     if ((e = hipMalloc((void**)&ctx->d_rays, sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc counter");
-    if ((e = hipMalloc((void**)&ctx->d_pick, sizeof(int))) != hipSuccess) return bail(e, "hipMalloc pick");
+    if ((e = hipMalloc((void**)&ctx->d_pick, 4 * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc pick");
     if ((e = hipMemsetAsync(ctx->d_fb_own, 0, px * sizeof(uint32_t), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
     if ((e = hipMemsetAsync(ctx->d_acc_own, 0, px * sizeof(float4), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
@@ -181,6 +189,8 @@ int srt_destroy(srt_context* ctx) {
     if (ctx->d_fb_own) (void)hipFree(ctx->d_fb_own);
     if (ctx->d_acc_own) (void)hipFree(ctx->d_acc_own);
     if (ctx->d_rays) (void)hipFree(ctx->d_rays);
+    if (ctx->d_bvh_nodes) (void)hipFree(ctx->d_bvh_nodes);
+    if (ctx->d_bvh_tris) (void)hipFree(ctx->d_bvh_tris);
     if (ctx->d_pick) (void)hipFree(ctx->d_pick);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
@@ -196,14 +206,20 @@ int srt_set_scene(srt_context* ctx, const srt_object* objects, size_t count) {
     SRT_HIP(ctx, hipSetDevice(ctx->device));
     for (size_t i = 0; i < count; ++i) {
         int t = objects[i].type;
-        if (t != SRT_OBJ_SPHERE && t != SRT_OBJ_BOX && t != SRT_OBJ_NONE)
+        if (t != SRT_OBJ_SPHERE && t != SRT_OBJ_BOX && t != SRT_OBJ_NONE && t != SRT_OBJ_MESH)
             return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: object %zu has unknown type %d", i, t);
+        if (t == SRT_OBJ_MESH && (objects[i].mesh < 0 || (size_t)objects[i].mesh >= ctx->meshes.size()))
+            return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: object %zu refers to mesh %d but %zu meshes are set (call srt_set_meshes first)",
+                        i, objects[i].mesh, ctx->meshes.size());
     }
     // the previous upload may still be in flight from h_scene
     SRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     static const bool no_cluster = getenv("SRT_NO_CLUSTER") != nullptr;
+    bool has_mesh = false;
+    for (size_t i = 0; i < count; ++i) has_mesh = has_mesh || objects[i].type == SRT_OBJ_MESH;
     for (int v = 0; v < 2; ++v) {
-        srt::SceneLayout L = srt::build_scene_image(objects, count, v == 0 && !no_cluster, ctx->h_scene[v]);
+        // with meshes both images are the same one, so that primitive ids agree with the BVH
+        srt::SceneLayout L = srt::build_scene_image(objects, count, (v == 0 || has_mesh) && !no_cluster, ctx->h_scene[v]);
         if ((size_t)L.total_vec4 * sizeof(float4) + srt::WG_SCRATCH_BYTES > (size_t)ctx->lds_limit_bytes || count >= 32768)
             return fail(ctx, SRT_ERR_INVALID_ARG,
                         "srt_set_scene: %d spheres + %d boxes need %zu B of LDS, limit %d B (tile streaming not built yet)",
@@ -218,7 +234,37 @@ int srt_set_scene(srt_context* ctx, const srt_object* objects, size_t count) {
                                     hipMemcpyHostToDevice, ctx->stream));
         ctx->layout[v] = L;
     }
+    // EXTENSION: flatten mesh objects into a world-space triangle list + BVH (HBM resident)
+    srt::build_mesh_image(objects, count, ctx->meshes, ctx->layout[0].nsT + ctx->layout[0].nb, ctx->mesh_image);
+    if (ctx->d_bvh_nodes) SRT_HIP(ctx, hipFree(ctx->d_bvh_nodes));
+    if (ctx->d_bvh_tris) SRT_HIP(ctx, hipFree(ctx->d_bvh_tris));
+    ctx->d_bvh_nodes = ctx->d_bvh_tris = nullptr;
+    if (ctx->mesh_image.n_tris > 0) {
+        if (ctx->mesh_image.max_depth > 26) return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: BVH too deep (%d)", ctx->mesh_image.max_depth);
+        SRT_HIP(ctx, hipMalloc((void**)&ctx->d_bvh_nodes, ctx->mesh_image.nodes.size() * sizeof(float4)));
+        SRT_HIP(ctx, hipMalloc((void**)&ctx->d_bvh_tris, ctx->mesh_image.tris.size() * sizeof(float4)));
+        SRT_HIP(ctx, hipMemcpyAsync(ctx->d_bvh_nodes, ctx->mesh_image.nodes.data(), ctx->mesh_image.nodes.size() * sizeof(float4),
+                                    hipMemcpyHostToDevice, ctx->stream));
+        SRT_HIP(ctx, hipMemcpyAsync(ctx->d_bvh_tris, ctx->mesh_image.tris.data(), ctx->mesh_image.tris.size() * sizeof(float4),
+                                    hipMemcpyHostToDevice, ctx->stream));
+    }
     ctx->scene_set = true;
+    return SRT_OK;
+}
+
+int srt_set_meshes(srt_context* ctx, const srt_mesh* meshes, size_t count) {
+    if (!ctx) return SRT_ERR_INVALID_ARG;
+    if (count && !meshes) return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_meshes: meshes is NULL");
+    std::vector<srt::HostMesh> copy(count);
+    for (size_t i = 0; i < count; ++i) {
+        const srt_mesh& m = meshes[i];
+        if ((m.vertex_count && !m.vertices) || (m.triangle_count && !m.indices))
+            return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_meshes: mesh %zu has NULL arrays", i);
+        if (m.triangle_count > (size_t)20000000) return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_meshes: mesh %zu is too large", i);
+        copy[i].vertices.assign(m.vertices, m.vertices + 3 * m.vertex_count);
+        copy[i].indices.assign(m.indices, m.indices + 3 * m.triangle_count);
+    }
+    ctx->meshes.swap(copy);
     return SRT_OK;
 }
 
@@ -316,6 +362,11 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
     K.off_mat = SL.off_mat;
     K.scene_vec4 = SL.total_vec4;
     K.scene = ctx->d_scene[img];
+    K.bvh_nodes = ctx->d_bvh_nodes;
+    K.bvh_tris = ctx->d_bvh_tris;
+    K.n_tris = ctx->mesh_image.n_tris;
+    for (int i = 0; i < 3; ++i) K.mesh_center[i] = ctx->mesh_image.center[i];
+    K.mesh_r1 = ctx->mesh_image.half[0] + ctx->mesh_image.half[1] + ctx->mesh_image.half[2];
     K.accumulator = ctx->d_acc;
     K.framebuffer = ctx->d_fb;
     K.ray_counter = ctx->d_rays;
@@ -354,12 +405,14 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     dim3 block(srt::WG_THREADS);
     SRT_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     // variants are a development aid for in-process A/B timing; all are bit-identical
-    if (use == 1)
-        hipLaunchKernelGGL(srt::pathtrace_kernel<5>, grid, block, lds_bytes, ctx->stream, K);
+    if (K.n_tris > 0)  // EXTENSION: scenes with triangle meshes use the BVH-enabled instantiation
+        hipLaunchKernelGGL((srt::pathtrace_kernel<4, true>), grid, block, lds_bytes, ctx->stream, K);
+    else if (use == 1)
+        hipLaunchKernelGGL((srt::pathtrace_kernel<5, false>), grid, block, lds_bytes, ctx->stream, K);
     else if (use == 3)
-        hipLaunchKernelGGL(srt::pathtrace_kernel<3>, grid, block, lds_bytes, ctx->stream, K);
+        hipLaunchKernelGGL((srt::pathtrace_kernel<3, false>), grid, block, lds_bytes, ctx->stream, K);
     else
-        hipLaunchKernelGGL(srt::pathtrace_kernel<4>, grid, block, lds_bytes, ctx->stream, K);
+        hipLaunchKernelGGL((srt::pathtrace_kernel<4, false>), grid, block, lds_bytes, ctx->stream, K);
     SRT_HIP(ctx, hipGetLastError());
     SRT_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
     ctx->launched = true;
@@ -370,6 +423,12 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
 
 // Development aid, not part of the public header: pick a kernel tuning variant for A/B
 // timing inside one process.  All variants produce identical bits.
+int srt_debug_last_pick(srt_context* ctx, int* out4) {
+    if (!ctx || !out4) return SRT_ERR_INVALID_ARG;
+    memcpy(out4, ctx->last_pick, sizeof ctx->last_pick);
+    return SRT_OK;
+}
+
 int srt_debug_set_variant(srt_context* ctx, int variant) {
     if (!ctx) return SRT_ERR_INVALID_ARG;
     ctx->variant = variant;
@@ -403,10 +462,11 @@ int srt_pick(srt_context* ctx, int x, int y, int* object_index) {
     int* d_out = ctx->d_pick;
     hipLaunchKernelGGL(srt::pick_kernel, dim3(1), dim3(64), lds_bytes, ctx->stream, K, x, y, d_out);
     SRT_HIP(ctx, hipGetLastError());
-    int idx = -1;
-    SRT_HIP(ctx, hipMemcpyAsync(&idx, d_out, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    int idx[4] = {-1, 0, 0, 0};
+    SRT_HIP(ctx, hipMemcpyAsync(idx, d_out, sizeof idx, hipMemcpyDeviceToHost, ctx->stream));
     SRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *object_index = idx;
+    *object_index = idx[0];
+    memcpy(ctx->last_pick, idx, sizeof idx);
     return SRT_OK;
 }
 

@@ -59,6 +59,12 @@ struct KernelParams {
     int32_t off_bounds, off_box, off_mat;
     int32_t scene_vec4;  // number of float4 in the scene image
     const float4* scene;
+    // EXTENSION: triangle meshes (srt_mesh_bvh.h); n_tris == 0 -> none
+    const float4* bvh_nodes;
+    const float4* bvh_tris;
+    int32_t n_tris;
+    float mesh_center[3];
+    float mesh_r1;  // L1 half extent of the root box
     float4* accumulator;
     uint32_t* framebuffer;
     unsigned long long* ray_counter;
@@ -191,7 +197,8 @@ __device__ __forceinline__ void hit_unkey(unsigned long long k, float& t, int& p
 //      fetch the ray with __shfl, run the EXACT sphere arithmetic and merge through a 64-bit
 //      LDS atomicMin on hit_key — so the wave does sum(pairs)/64 rounds, not max-per-lane.
 //   3. boxes: every lane, exact arithmetic.
-__device__ __forceinline__ Hit closest_hit(const Lds& S, V3 o, V3 d, bool active) {
+template <bool MESH>
+__device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, V3 o, V3 d, bool active) {
     float best = __builtin_inff();
     int bp = -1;
     // exact sphere test of ray (ro, rd) against four spheres; updates (tb, pb) with the tie rule.
@@ -214,14 +221,13 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, V3 o, V3 d, bool active
     auto part2 = [&](const Cand& k, int p, float& tb, int& pb) {
         if (__builtin_amdgcn_ballot_w64(k.c) != 0ull) {
             float t1 = k.tc - sqrtf(k.x);  // :131-133
-            if (k.c) {
-                if (t1 < tb) {  // Raytracer.cpp:130-132
-                    tb = t1;
-                    pb = p;
-                } else if (t1 == tb && pb >= 0 && S.order(p) < S.order(pb)) {
-                    pb = p;  // same distance, earlier in ObjectsToRender
-                }
-            }
+            // Raytracer.cpp:130-132; on an exact tie the earlier entry of ObjectsToRender wins.
+            // Branch-free on purpose (see the note in the triangle phase).
+            const bool tie = k.c & (t1 == tb) & (pb >= 0);
+            const int op = S.order(p), ob = S.order(tie ? pb : p);
+            const bool win = k.c & ((t1 < tb) | (tie & (op < ob)));
+            tb = win ? t1 : tb;
+            pb = win ? p : pb;
         }
     };
     auto test4 = [&](const float4 s0, const float4 s1, const float4 s2, const float4 s3, int p, V3 ro, V3 rd, bool on, float& tb,
@@ -333,10 +339,91 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, V3 o, V3 d, bool active
             float dist = ibox_dist(br, v3(o.x - c.x, o.y - c.y, o.z - c.z), v3(hs.x, hs.y, hs.z), t1);
             bool valid = active && dist != 3.402823466e+38f;  // Object.hpp:231
             if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
-                if (valid && (dist < best || (dist == best && bp >= 0 && S.order(nsT + j) < S.order(bp)))) {
-                    best = dist;
-                    bp = nsT + j;
-                    bt1 = t1;
+                const bool tie = valid & (dist == best) & (bp >= 0);
+                const int ob = S.order(tie ? bp : nsT + j);
+                const bool win = valid & ((dist < best) | (tie & (S.order(nsT + j) < ob)));
+                best = win ? dist : best;
+                bp = win ? nsT + j : bp;
+                bt1 = win ? t1 : bt1;
+            }
+        }
+    }
+    // ---- 4. EXTENSION: triangle meshes — per-lane traversal of the host-built BVH (HBM/L2).
+    // The triangle arithmetic is this project's definition (srt_pathtrace.h); the box filter is
+    // conservative: boxes are padded per ray by 1e-5 * (distance of the origin to the mesh +
+    // mesh size), far above the rounding of the Moller-Trumbore test (~1e-6 * |o - v0|), and the
+    // slab comparison itself has slack for the approximate reciprocals.
+    int btri = -1;               // winner's position in the triangle array (-1: not a triangle)
+    int bgid = 0x7fffffff;       // its global triangle id
+    int bord = 0x7fffffff;       // list index of the current best hit's object (registers only in the traversal)
+    if constexpr (MESH) {
+        if (P.n_tris > 0) {
+            if (bp >= 0) bord = S.order(bp);
+            const float pad = 1e-5f * (((fabsf(o.x - P.mesh_center[0]) + fabsf(o.y - P.mesh_center[1])) + fabsf(o.z - P.mesh_center[2])) + P.mesh_r1) + 1e-7f;
+            const V3 inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+            int stack[28];
+            int sp = 0, node = 0;
+            bool go = active;
+            while (__builtin_amdgcn_ballot_w64(go) != 0ull) {
+                if (go) {
+                    const float4 n0 = P.bvh_nodes[2 * node], n1 = P.bvh_nodes[2 * node + 1];
+                    // NaN-suppressing slab test (v_min/v_max return the non-NaN operand)
+                    float t1x = ((n0.x - pad) - o.x) * inv.x, t2x = ((n1.x + pad) - o.x) * inv.x;
+                    float t1y = ((n0.y - pad) - o.y) * inv.y, t2y = ((n1.y + pad) - o.y) * inv.y;
+                    float t1z = ((n0.z - pad) - o.z) * inv.z, t2z = ((n1.z + pad) - o.z) * inv.z;
+                    float tmin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+                    float tmax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+                    const bool boxhit = tmin <= tmax * 1.00001f + 1e-6f && tmax >= 0.0f && tmin * 0.9999f - 1e-5f <= best && tmin <= 10001.0f;
+                    const int cnt = __float_as_int(n1.w);
+                    bool pop = true;
+                    if (boxhit) {
+                        if (cnt > 0) {  // leaf: up to 4 triangles
+                            const int first = __float_as_int(n0.w);
+                            for (int k = 0; k < 4; ++k) {
+                                if (k < cnt) {
+                                    const float4 a = P.bvh_tris[3 * (first + k)], b = P.bvh_tris[3 * (first + k) + 1], c = P.bvh_tris[3 * (first + k) + 2];
+                                    // Moller-Trumbore, binary32, no FMA, fixed order (the oracle's triangle_raytrace)
+                                    V3 pv = v3(d.y * c.z - d.z * c.y, d.z * c.x - d.x * c.z, d.x * c.y - d.y * c.x);
+                                    float det = (b.x * pv.x + b.y * pv.y) + b.z * pv.z;
+                                    if (fabsf(det) >= 1e-12f) {
+                                        float idet = 1.0f / det;
+                                        V3 tv = v3(o.x - a.x, o.y - a.y, o.z - a.z);
+                                        float u = ((tv.x * pv.x + tv.y * pv.y) + tv.z * pv.z) * idet;
+                                        if (u >= 0.0f && u <= 1.0f) {
+                                            V3 qv = v3(tv.y * b.z - tv.z * b.y, tv.z * b.x - tv.x * b.z, tv.x * b.y - tv.y * b.x);
+                                            float vv = ((d.x * qv.x + d.y * qv.y) + d.z * qv.z) * idet;
+                                            if (vv >= 0.0f && u + vv <= 1.0f) {
+                                                float t = ((c.x * qv.x + c.y * qv.y) + c.z * qv.z) * idet;
+                                                if (t >= (float)0.01 && t <= 10000.0f) {
+                                                    const int ord = __float_as_int(c.w), gid = __float_as_int(b.w);
+                                                    // (distance, list index, triangle id) lexicographic minimum.  Written as
+                                                    // branch-free boolean algebra + selects on purpose: hipcc (ROCm 7.2) lowers the
+                                                    // nested short-circuit form of this update into exec-mask code that loses one of
+                                                    // the state updates for lanes winning through the tie term (seen in the ISA).
+                                                    const bool win = (t < best) | ((t == best) & ((ord < bord) | ((ord == bord) & (gid < bgid))));
+                                                    best = win ? t : best;
+                                                    bp = win ? __float_as_int(a.w) : bp;
+                                                    btri = win ? first + k : btri;
+                                                    bgid = win ? gid : bgid;
+                                                    bord = win ? ord : bord;
+                                                }
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                        } else {  // inner node: left child is node + 1, right child goes on the stack
+                            stack[sp++] = __float_as_int(n0.w);
+                            node = node + 1;
+                            pop = false;
+                        }
+                    }
+                    if (pop) {
+                        if (sp == 0)
+                            go = false;
+                        else
+                            node = stack[--sp];
+                    }
                 }
             }
         }
@@ -344,7 +431,12 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, V3 o, V3 d, bool active
     h.t = best;
     h.prim = bp;
     h.p = v3(o.x + d.x * best, o.y + d.y * best, o.z + d.z * best);  // Object.hpp:136 / :229
-    if (bp >= nsT) {
+    if (MESH && btri >= 0) {
+        const float4 b = P.bvh_tris[3 * btri + 1], c = P.bvh_tris[3 * btri + 2];
+        V3 n = normalized(v3(b.y * c.z - b.z * c.y, b.z * c.x - b.x * c.z, b.x * c.y - b.y * c.x));  // unit geometric normal
+        if (dot3(n, d) > 0) n = v3(n.x * -1, n.y * -1, n.z * -1);                                      // turned against the ray
+        h.n = n;
+    } else if (bp >= nsT) {
         h.n = ibox_normal(br, bt1);
     } else if (bp >= 0) {
         const float4 s = S.sphere(bp);
@@ -398,7 +490,7 @@ __device__ __forceinline__ uint32_t pack_channel(float v) {  // Common.hpp:190-2
     return (uint32_t)(uint8_t)s;
 }
 
-template <int MIN_WAVES>
+template <int MIN_WAVES, bool MESH>
 __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const KernelParams P) {
     extern __shared__ float4 lds_scene[];
     // ---- stage the scene image into LDS (coalesced 16-byte loads) -----------------
@@ -438,7 +530,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     const V3 cam = v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
 
     // ---- primary hit: identical for every sample ------------------------------------
-    const Hit h0 = closest_hit(S, cam, dir0, true);
+    const Hit h0 = closest_hit<MESH>(S, P, cam, dir0, true);
 
     const bool reset = (P.flags & 1u) != 0;
     const uint32_t count = P.sample_count;
@@ -659,7 +751,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 o = v3(hp.x + hn.x * ofs, hp.y + hn.y * ofs, hp.z + hn.z * ofs);  // :177
             }
             // the scan runs in wave-uniform control flow: idle lanes help with other lanes' rays
-            const Hit h = closest_hit(S, o, sray, busy);
+            const Hit h = closest_hit<MESH>(S, P, o, sray, busy);
             if (busy) {
                 ++rays;
                 bool end_path;
@@ -715,8 +807,13 @@ __global__ void __launch_bounds__(64) pick_kernel(const KernelParams P, int px, 
     V3 u = v3(P.right_rd[0] * nX, P.right_rd[1] * nX, P.right_rd[2] * nX);
     V3 vv = v3(P.up_ld[0] * nY, P.up_ld[1] * nY, P.up_ld[2] * nY);
     const V3 dir = normalized(v3((u.x + vv.x) + P.fwd_clip[0], (u.y + vv.y) + P.fwd_clip[1], (u.z + vv.z) + P.fwd_clip[2]));
-    const Hit h = closest_hit(S, v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]), dir, true);
-    if (threadIdx.x == 0) *out_index = h.prim >= 0 ? S.order(h.prim) : -1;
+    const Hit h = closest_hit<true>(S, P, v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]), dir, true);
+    if (threadIdx.x == 0) {
+        out_index[0] = h.prim >= 0 ? S.order(h.prim) : -1;
+        out_index[1] = __float_as_int(h.t);
+        out_index[2] = h.prim;
+        out_index[3] = __float_as_int(h.n.z);
+    }
 }
 
 }  // namespace srt

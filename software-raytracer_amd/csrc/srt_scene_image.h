@@ -12,8 +12,8 @@
 //                            inflated so that the kernel's cheap test is CONSERVATIVE with
 //                            respect to the reference's float arithmetic (proof below).
 //   [.., +2nb)               boxes (cx,cy,cz,_)(hx,hy,hz,_), list order.
-//   [off_mat, +3(nsT+nb))    three material rows per primitive id p (spheres: p = index in
-//                            [0,nsT); boxes: p = nsT + j):
+//   [off_mat, +3(nsT+nb+nm)) three material rows per primitive id p (spheres: p = index in
+//                            [0,nsT); boxes: p = nsT + j; mesh objects: p = nsT + nb + m):
 //                              (smoothness, specular_amount, base.r, base.g)
 //                              (base.b, emissive.r, emissive.g, emissive.b)
 //                              (specular.r, specular.g, specular.b, bits(list index))
@@ -59,6 +59,7 @@ struct SceneLayout {
     int K = 4;        // sphere slots per cluster (multiple of 4)
     int nsT = 0;      // nu4 + nc*K
     int nb = 0;       // boxes
+    int nm = 0;       // mesh objects (EXTENSION): primitive ids nsT + nb + m, geometry lives in the BVH
     int off_bounds = 0, off_box = 0, off_mat = 0;
     int total_vec4 = 0;
     int n_spheres = 0;  // real spheres (for statistics)
@@ -78,10 +79,11 @@ inline uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) {  // 10 bits per ax
 
 // Builds the image. `cluster` = false puts every sphere in the uniform block.
 inline SceneLayout build_scene_image(const srt_object* objects, size_t count, bool cluster, std::vector<float4>& img) {
-    std::vector<int> spheres, boxes;
+    std::vector<int> spheres, boxes, meshobjs;
     for (size_t i = 0; i < count; ++i) {
         if (objects[i].type == SRT_OBJ_SPHERE) spheres.push_back((int)i);
         if (objects[i].type == SRT_OBJ_BOX) boxes.push_back((int)i);
+        if (objects[i].type == SRT_OBJ_MESH) meshobjs.push_back((int)i);
     }
     auto finite_sphere = [&](int i) {
         const srt_object& o = objects[i];
@@ -114,6 +116,7 @@ inline SceneLayout build_scene_image(const srt_object* objects, size_t count, bo
     SceneLayout L;
     L.n_spheres = (int)spheres.size();
     L.nb = (int)boxes.size();
+    L.nm = (int)meshobjs.size();
     L.nu4 = ((int)uni.size() + 3) & ~3;
     // order the small spheres along a Morton curve of their centres, then cut into clusters
     if (!small.empty()) {
@@ -144,7 +147,7 @@ inline SceneLayout build_scene_image(const srt_object* objects, size_t count, bo
     L.off_bounds = L.nsT;
     L.off_box = L.off_bounds + L.nc;
     L.off_mat = L.off_box + 2 * L.nb;
-    L.total_vec4 = L.off_mat + 3 * (L.nsT + L.nb);
+    L.total_vec4 = L.off_mat + 3 * (L.nsT + L.nb + L.nm);
 
     img.assign((size_t)std::max(L.total_vec4, 1), make_float4(0, 0, 0, 0));
     const float4 dummy = make_float4(0, 0, 0, -1.0f);  // d2 > r*r always: never a candidate
@@ -191,6 +194,7 @@ inline SceneLayout build_scene_image(const srt_object* objects, size_t count, bo
         img[L.off_box + 2 * j + 1] = make_float4(o.half_size[0], o.half_size[1], o.half_size[2], 0.0f);
         put_material(L.nsT + (int)j, boxes[j]);
     }
+    for (size_t m = 0; m < meshobjs.size(); ++m) put_material(L.nsT + L.nb + (int)m, meshobjs[m]);
     return L;
 }
 

@@ -7,14 +7,14 @@ import subprocess
 
 import numpy as np
 
-from .capi import Object, Stats
+from .capi import Mesh, Object, Stats
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_PKG, "libsrt_host.so")
 
 EXPORTS = [
     "srt_host_scene_load", "srt_host_scene_new", "srt_host_scene_free", "srt_host_scene_count",
-    "srt_host_scene_objects", "srt_host_scene_error", "srt_host_scene_name", "srt_host_scene_object_name",
+    "srt_host_scene_objects", "srt_host_scene_mesh_count", "srt_host_scene_mesh", "srt_host_scene_error", "srt_host_scene_name", "srt_host_scene_object_name",
     "srt_host_scene_add", "srt_host_scene_remove", "srt_host_scene_save_as", "srt_host_scene_dump",
     "srt_host_format_double", "srt_host_rotate_about_axis", "srt_host_last_error",
     "srt_host_renderer_create", "srt_host_renderer_destroy", "srt_host_renderer_set_scene",
@@ -51,6 +51,9 @@ def load_library():
     L.srt_host_scene_count.restype = C.c_size_t
     L.srt_host_scene_objects.argtypes = [vp]
     L.srt_host_scene_objects.restype = C.POINTER(Object)
+    L.srt_host_scene_mesh_count.argtypes = [vp]
+    L.srt_host_scene_mesh_count.restype = C.c_size_t
+    L.srt_host_scene_mesh.argtypes = [vp, C.c_size_t, C.POINTER(Mesh)]
     for n in ("srt_host_scene_error", "srt_host_scene_name", "srt_host_scene_dump"):
         getattr(L, n).argtypes = [vp]
         getattr(L, n).restype = C.c_char_p
@@ -136,6 +139,14 @@ class Scene:
         arr = (Object * max(n, 1))()
         for i in range(n):
             arr[i] = ptr[i]
+        return arr, n
+
+    def meshes(self):
+        """EXTENSION: (ctypes Mesh array, count) of the scene's "Mesh" renderers (pointers into the scene)."""
+        n = self.L.srt_host_scene_mesh_count(self._h)
+        arr = (Mesh * max(n, 1))()
+        for i in range(n):
+            self.L.srt_host_scene_mesh(self._h, i, C.byref(arr[i]))
         return arr, n
 
     def add(self, obj, name=""):

@@ -36,6 +36,14 @@ const srt_object* srt_host_scene_objects(srt_host_scene* s) {
     s->flat = s->scene.Flatten();
     return s->flat.data();
 }
+// EXTENSION: geometry of the scene's Mesh objects (index = srt_object.mesh); valid until the scene changes
+size_t srt_host_scene_mesh_count(srt_host_scene* s) { return s->scene.MeshViews().size(); }
+int srt_host_scene_mesh(srt_host_scene* s, size_t i, srt_mesh* out) {
+    std::vector<srt_mesh> v = s->scene.MeshViews();
+    if (i >= v.size()) return 1;
+    *out = v[i];
+    return 0;
+}
 const char* srt_host_scene_error(const srt_host_scene* s) { return s->scene.lastError().c_str(); }
 const char* srt_host_scene_name(const srt_host_scene* s) { return s->scene.sceneName.c_str(); }
 const char* srt_host_scene_object_name(const srt_host_scene* s, size_t i) {

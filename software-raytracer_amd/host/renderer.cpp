@@ -23,6 +23,8 @@ PathTraceRenderer::~PathTraceRenderer() { srt_destroy(ctx_); }
 
 void PathTraceRenderer::SetScene(const Scene& scene) {
     std::vector<srt_object> flat = scene.Flatten();
+    std::vector<srt_mesh> meshes = scene.MeshViews();  // EXTENSION: geometry of "Mesh" renderers
+    check(srt_set_meshes(ctx_, meshes.data(), meshes.size()), "srt_set_meshes");
     check(srt_set_scene(ctx_, flat.data(), flat.size()), "srt_set_scene");
     doSetFrame_ = true;
 }

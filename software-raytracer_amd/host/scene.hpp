@@ -36,7 +36,7 @@ struct Material {  // Common.hpp:293-319
     Color3 SpecularColor{1, 1, 1};
 };
 
-enum class RendererType { None = SRT_OBJ_NONE, Sphere = SRT_OBJ_SPHERE, Cube = SRT_OBJ_BOX };
+enum class RendererType { None = SRT_OBJ_NONE, Sphere = SRT_OBJ_SPHERE, Cube = SRT_OBJ_BOX, Mesh = SRT_OBJ_MESH /* EXTENSION */ };
 
 struct SceneObject {  // Object / Sphere / Box data members
     RendererType type = RendererType::None;
@@ -45,9 +45,17 @@ struct SceneObject {  // Object / Sphere / Box data members
     float radius = 0;               // Sphere::radius
     float size[3] = {0, 0, 0};      // Box::size (half extents)
     Material material;
+    // EXTENSION — "Renderer": {"Type": "Mesh", ...} (the reference's loader treats an unknown
+    // type as an inert Object, Scene.hpp:53-55, so old readers degrade gracefully):
+    //   explicit:    "Vertices": [x0,y0,z0, x1,...], "Indices": [i0,j0,k0, ...]
+    //   procedural:  "Primitive": "UVSphere", "Radius": r, "Stacks": n, "Slices": m
+    std::string meshPrimitive;      // "" = explicit arrays
+    int meshStacks = 0, meshSlices = 0;
+    std::vector<float> meshVertices;
+    std::vector<uint32_t> meshIndices;
 
     Json ToJSON() const;            // Object.hpp:27-43 (+ :143-147 / :218-222)
-    srt_object Flatten() const;     // -> C-ABI element
+    srt_object Flatten() const;     // -> C-ABI element (mesh index filled in by Scene::Flatten)
 };
 
 class Scene {
@@ -72,8 +80,10 @@ class Scene {
     bool RemoveObject(size_t index);                                      // :108-115 (by identity there)
 
     std::string Dump() const;  // the exact bytes Save() writes
-    // ObjectsToRender (Raytracer.cpp:61,293) as the C-ABI array, list order kept
+    // ObjectsToRender (Raytracer.cpp:61,293) as the C-ABI array, list order kept; mesh objects
+    // get mesh = their ordinal among mesh objects, matching MeshViews()
     std::vector<srt_object> Flatten() const;
+    std::vector<srt_mesh> MeshViews() const;  // pointers into this scene's objects
     const std::string& lastError() const { return error_; }
 
    private:
@@ -81,5 +91,8 @@ class Scene {
     std::vector<SceneObject> sceneObjects;
     std::string error_;
 };
+
+// Deterministic latitude/longitude tessellation (BASELINE config 4: 224 x 224 -> 99,904 triangles)
+void MakeUVSphere(float radius, int stacks, int slices, std::vector<float>& vertices, std::vector<uint32_t>& indices);
 
 }  // namespace srt_host

@@ -25,7 +25,7 @@ def test_header_symbols_exported(srt):
 
 def test_struct_layouts_match_header(srt):
     # sizes the header implies (all 4-byte fields, no padding)
-    assert C.sizeof(srt.Material) == 44 and C.sizeof(srt.Object) == 76
+    assert C.sizeof(srt.Material) == 44 and C.sizeof(srt.Object) == 80
     assert C.sizeof(srt.Environment) == 60 and C.sizeof(srt.Camera) == 52 and C.sizeof(srt.RenderParams) == 40
 
 

@@ -1,0 +1,161 @@
+"""EXTENSION (BASELINE configs 4-5): triangle meshes.  The reference has no triangle primitive, so
+parity here is HIP (host-built BVH, per-lane traversal) vs this project's own brute-force oracle
+definition — bit-exact like everything else, but unpinned by any reference."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import scene_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene1_with_mesh(oracle, stacks, slices, extra=()):
+    objs = oracle.load_scene_json_py(scene_path("Scene1"))
+    big = objs[64]  # the r = 1 "big ball" at (0,0,5)
+    objs[64] = dict(type=oracle.OBJ_MESH, position=big["position"], mesh=0, base=big["base"], emissive=big["emissive"],
+                    smoothness=big["smoothness"], specular_amount=big["specular_amount"], specular=big["specular"])
+    objs += list(extra)
+    V, T = oracle.uv_sphere(1.0, stacks, slices)
+    return objs, [(V, T)]
+
+
+def _render_both(srt, oracle, objs, meshes, w, h, **kw):
+    oarr, n = oracle.make_objects(objs)
+    marr, mn, keep = oracle.make_meshes(meshes)
+    pt = srt.PathTracer(w, h)
+    pt.set_meshes(C.cast(marr, C.POINTER(srt.Mesh)), mn)
+    pt.set_scene(C.cast(oarr, C.POINTER(srt.Object)), n)
+    pt.set_camera(srt.default_camera())
+    pt.render(count_rays=True, **kw)
+    fb, acc, st = pt.framebuffer(), pt.accumulator(), pt.stats()
+    ofb, oacc, orays = oracle.render(oarr, n, oracle.default_environment(), oracle.default_camera(), w, h, meshes=(marr, mn), **kw)
+    return pt, (fb, acc, st.rays), (ofb, oacc, orays), keep
+
+
+@pytest.mark.parametrize("stacks,slices,w,h,spp,bounces", [(8, 12, 160, 90, 2, 4), (24, 32, 128, 72, 2, 8), (48, 64, 96, 54, 1, 8)])
+def test_mesh_scene_bit_exact_vs_bruteforce_oracle(srt, oracle, stacks, slices, w, h, spp, bounces):
+    objs, meshes = _scene1_with_mesh(oracle, stacks, slices)
+    pt, g, o, keep = _render_both(srt, oracle, objs, meshes, w, h, spp=spp, bounces=bounces, seed=1)
+    assert g[2] == o[2]
+    assert np.array_equal(g[1].view(np.uint32), o[1].view(np.uint32)), int((g[1].view(np.uint32) != o[1].view(np.uint32)).sum())
+    assert np.array_equal(g[0], o[0])
+    # picking sees the mesh object (list index 64) in the image centre
+    assert pt.pick(w // 2, h // 2) == 64
+    pt.close()
+
+
+def test_two_meshes_boxes_and_ties(srt, oracle):
+    """Two instances of one mesh, one coincident with a sphere and overlapping a box: list-order
+    tie rules across primitive kinds."""
+    objs = oracle.load_scene_json_py(scene_path("Scene_indirect"))
+    V, T = oracle.uv_sphere(0.8, 10, 14)
+    cube_v = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], np.float32) * 0.5
+    cube_t = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [2, 3, 7], [2, 7, 6], [1, 2, 6], [1, 6, 5], [0, 4, 7], [0, 7, 3]], np.uint32)
+    objs.insert(3, dict(type=oracle.OBJ_MESH, position=(0.6, -0.3, 3.0), mesh=0, base=(.9, .2, .2), specular_amount=0.5, smoothness=0.9))
+    objs.append(dict(type=oracle.OBJ_MESH, position=(-0.9, 0.1, 3.5), mesh=1, base=(.2, .9, .2), emissive=(0.5, 0.5, 0.0)))
+    objs.append(dict(type=oracle.OBJ_BOX, position=(-0.9, 0.1, 3.5), half_size=(0.5, 0.5, 0.5), base=(.2, .2, .9)))  # same faces as the cube mesh
+    objs.append(dict(type=oracle.OBJ_MESH, position=(0.6, -0.3, 3.0), mesh=0, base=(.1, .1, .1)))                   # exact duplicate of object 3
+    pt, g, o, keep = _render_both(srt, oracle, objs, [(V, T), (cube_v, cube_t)], 144, 81, spp=2, bounces=6, seed=4)
+    assert g[2] == o[2]
+    assert np.array_equal(g[1].view(np.uint32), o[1].view(np.uint32))
+    assert np.array_equal(g[0], o[0])
+    pt.close()
+
+
+def test_config4_100k_triangles_small_frame_vs_oracle_and_full_size_properties(srt, oracle):
+    """BASELINE configs[3]: Scene1 with the big ball tessellated 224 x 224 -> 99,904 triangles.
+    Brute-force oracle at a tiny frame (it scans all 100k triangles per ray); at 1920x1080 the
+    size-independent properties: determinism, band concatenation, resume == one shot."""
+    objs, meshes = _scene1_with_mesh(oracle, 224, 224)
+    assert meshes[0][1].shape[0] == 99904
+    pt, g, o, keep = _render_both(srt, oracle, objs, meshes, 48, 27, spp=1, bounces=8, seed=0)
+    assert g[2] == o[2] and np.array_equal(g[0], o[0]) and np.array_equal(g[1].view(np.uint32), o[1].view(np.uint32))
+    pt.close()
+    oarr, n = oracle.make_objects(objs)
+    marr, mn, keep = oracle.make_meshes(meshes)
+    W, H = 1920, 1080
+    pt = srt.PathTracer(W, H)
+    pt.set_meshes(C.cast(marr, C.POINTER(srt.Mesh)), mn)
+    pt.set_scene(C.cast(oarr, C.POINTER(srt.Object)), n)
+    pt.set_camera(srt.default_camera())
+    pt.render(spp=8, bounces=8, seed=0)
+    a = pt.framebuffer()
+    pt.render(spp=8, bounces=8, seed=0)
+    assert np.array_equal(pt.framebuffer(), a)
+    for rb, re in [(0, 400), (400, 700), (700, 1080)]:
+        pt.render(spp=8, bounces=8, seed=0, rows=(rb, re))
+        assert np.array_equal(pt.framebuffer(rows=(rb, re)), a[rb:re])
+    pt.render(spp=5, bounces=8, seed=0)
+    pt.render(spp=3, bounces=8, seed=0, first_sample=6, reset=False)
+    assert np.array_equal(pt.framebuffer(), a)
+    # the tessellated ball must look like the analytic one: PSNR of the two renders
+    sobjs = oracle.load_scene_json_py(scene_path("Scene1"))
+    sarr, sn = oracle.make_objects(sobjs)
+    ps = srt.PathTracer(W, H)
+    ps.set_scene(C.cast(sarr, C.POINTER(srt.Object)), sn)
+    ps.set_camera(srt.default_camera())
+    ps.render(spp=8, bounces=8, seed=0)
+    b = ps.framebuffer()
+    ch = lambda f: np.stack([(f >> 16) & 255, (f >> 8) & 255, f & 255], -1).astype(np.float64)
+    mse = ((ch(a) - ch(b)) ** 2).mean()
+    psnr = 10 * np.log10(255 ** 2 / mse)
+    assert psnr > 25, psnr
+
+
+@pytest.mark.parametrize("ncopy", [2, 3, 5])
+def test_identical_mesh_copies_tie_to_the_first(srt, oracle, ncopy):
+    """N exact copies of one mesh at the same place: every hit is an N-way tie in distance and must
+    resolve to the first object (Raytracer.cpp:132's strict '<').  Regression: hipcc lowered the
+    nested short-circuit form of the tie update into exec-mask code that lost a state update."""
+    V, T = oracle.uv_sphere(0.8, 10, 14)
+    objs = [dict(type=oracle.OBJ_NONE)] + [dict(type=oracle.OBJ_MESH, position=(0, 0, 4), mesh=0) for _ in range(ncopy)]
+    oarr, n = oracle.make_objects(objs)
+    marr, mn, keep = oracle.make_meshes([(V, T)])
+    pt = srt.PathTracer(64, 64)
+    pt.set_meshes(C.cast(marr, C.POINTER(srt.Mesh)), mn)
+    pt.set_scene(C.cast(oarr, C.POINTER(srt.Object)), n)
+    pt.set_camera(srt.default_camera())
+    picks = {pt.pick(x, y) for x in range(16, 48, 2) for y in range(16, 48, 2)}
+    assert picks == {-1, 1}
+    pt.close()
+
+
+def test_host_scene_with_mesh_renderer(srt, oracle, tmp_path):
+    """The C++ host loads "Renderer": {"Type": "Mesh", ...} (procedural UVSphere and explicit arrays),
+    hands the geometry to srt_set_meshes, and the frame equals the oracle's."""
+    import json
+
+    scene = json.load(open(scene_path("Scene2")))
+    objs = scene["SceneObjects"]
+    objs[64]["Renderer"] = {"Type": "Mesh", "Primitive": "UVSphere", "Radius": 1.0, "Stacks": 12, "Slices": 16}
+    quad = {"Name": "quad", "Position": [-1.5, 0.2, 4.0], "Material": {"Color": [0.9, 0.1, 0.1], "Emissive": [0.2, 0.0, 0.0]},
+            "Renderer": {"Type": "Mesh", "Vertices": [-0.5, -0.5, 0, 0.5, -0.5, 0, 0.5, 0.5, 0, -0.5, 0.5, 0], "Indices": [0, 2, 1, 0, 3, 2]}}
+    objs.append(quad)
+    p = tmp_path / "mesh_scene.json"
+    p.write_text(json.dumps(scene))
+    s = srt.host.Scene(str(p))
+    assert s.error == "" and len(s) == len(objs)
+    marr, mn = s.meshes()
+    assert mn == 2 and marr[0].triangle_count == 2 * 16 * 11 and marr[1].triangle_count == 2
+    # the C++ generator equals the python one bit for bit
+    V, T = oracle.uv_sphere(1.0, 12, 16)
+    assert np.array_equal(np.ctypeslib.as_array(marr[0].vertices, (marr[0].vertex_count, 3)), V)
+    assert np.array_equal(np.ctypeslib.as_array(marr[0].indices, (marr[0].triangle_count, 3)), T)
+    w, h = 128, 72
+    r = srt.host.Renderer(w, h)
+    r.settings(fov=55, max_bounces=4, target_frames=64, seed=2)
+    r.set_scene(s)
+    r.render_samples(2)
+    optr, on = s.objects()
+    ofb, oacc, _ = oracle.render(C.cast(optr, C.POINTER(oracle.Object)), on, oracle.default_environment(), oracle.default_camera(), w, h,
+                                 spp=2, bounces=4, seed=2, meshes=(C.cast(marr, C.POINTER(oracle.Mesh)), mn))
+    assert np.array_equal(r.framebuffer(), ofb) and np.array_equal(r.accumulator().view(np.uint32), oacc.view(np.uint32))
+    # save -> load round trip keeps the mesh renderers
+    out = tmp_path / "resaved.json"
+    s.save_as(str(out))
+    d = json.load(open(out))
+    assert d["SceneObjects"][64]["Renderer"] == {"Primitive": "UVSphere", "Radius": 1.0, "Slices": 16, "Stacks": 12, "Type": "Mesh"}
+    assert d["SceneObjects"][-1]["Renderer"]["Indices"] == [0, 2, 1, 0, 3, 2]
+    r.close()

@@ -271,3 +271,38 @@ def test_block_anchor_formula_equals_the_literal_loop_nest(oracle):
                 assert lit[2] < fm[2]  # the literal walk traces one ray per block, the formula one per pixel
             # blocks really replicate: pixel (1,1) equals its anchor (0,0) when steps > 1
             assert np.array_equal(fm[1][0, 0], fm[1][1, 1])
+
+
+# ---- EXTENSION: triangle test (this project's definition, srt_pathtrace.h) -------------------
+def test_triangle_known_answers(oracle):
+    L = oracle.lib()
+    L.srt_oracle_triangle.argtypes = [C.POINTER(C.c_float)] * 7 + [C.POINTER(C.c_float)]
+    L.srt_oracle_triangle.restype = C.c_int
+
+    def tri(v0, v1, v2, o, d):
+        n, p, t = f3((0, 0, 0)), f3((0, 0, 0)), C.c_float(0)
+        ok = L.srt_oracle_triangle(f3(v0), f3(v1), f3(v2), f3(o), f3(d), n, p, C.byref(t))
+        return ok, list(n), list(p), t.value
+
+    A, B, Cc = (-1, -1, 4), (1, -1, 4), (0, 1, 4)
+    ok, n, p, t = tri(A, B, Cc, (0, 0, 0), (0, 0, 1))
+    assert ok == 1 and t == 4.0 and p == [0, 0, 4] and n == [0, 0, -1]        # normal turned against the ray
+    ok, n, p, t = tri(A, Cc, B, (0, 0, 0), (0, 0, 1))
+    assert ok == 1 and n == [0, 0, -1]                                        # winding does not matter (two-sided)
+    assert tri(A, B, Cc, (0, 0, 0), (0, 0, -1))[0] == 0                       # behind the origin
+    assert tri(A, B, Cc, (3, 0, 0), (0, 0, 1))[0] == 0                        # outside
+    assert tri(A, B, Cc, (0, 0, 3.995), (0, 0, 1))[0] == 0                    # t < 0.01 (the Box bound, Object.hpp:226)
+    assert tri(A, B, Cc, (0, 0, 0), (1, 0, 0))[0] == 0                        # parallel
+    ok, n, p, t = tri(A, B, Cc, (0, -1, 0), (0, 0, 1))
+    assert ok == 1 and t == 4.0                                               # on the edge v = 0 counts as a hit
+
+
+def test_uv_sphere_generator(oracle):
+    V, T = oracle.uv_sphere(1.0, 224, 224)
+    assert T.shape == (99904, 3) and V.shape == (2 + 223 * 224, 3)
+    r = np.linalg.norm(V.astype(np.float64), axis=1)
+    assert np.abs(r - 1).max() < 1e-6
+    # outward winding: normals point away from the centre
+    a, b, c = V[T[:, 0]].astype(np.float64), V[T[:, 1]].astype(np.float64), V[T[:, 2]].astype(np.float64)
+    nrm = np.cross(b - a, c - a)
+    assert (np.einsum("ij,ij->i", nrm, (a + b + c) / 3) > 0).all()
