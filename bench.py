@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU sample")
     ap.add_argument("--balance", default="cost", choices=["cost", "equal"], help="row-stripe split for N>1")
+    ap.add_argument("--mesh", type=int, default=0, metavar="N",
+                    help="EXTENSION workload (BASELINE configs[3]): replace Scene1's big ball by an N x N lat-long "
+                         "tessellation (224 -> 99,904 triangles); implies --no-cpu-baseline")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,12 +110,28 @@ def main():
 
     W, H = args.width, args.height
     spp = args.spp * world
-    scene = srt.host.Scene(os.path.join(ROOT, "software-raytracer_amd", "scenes", args.scene + ".json"))
+    scene_file = os.path.join(ROOT, "software-raytracer_amd", "scenes", args.scene + ".json")
+    if args.mesh:
+        import tempfile
+
+        sj = json.load(open(scene_file))
+        sj["SceneObjects"][64]["Renderer"] = {"Type": "Mesh", "Primitive": "UVSphere", "Radius": 1.0, "Stacks": args.mesh, "Slices": args.mesh}
+        tmp = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
+        json.dump(sj, tmp)
+        tmp.close()
+        scene_file = tmp.name
+        args.no_cpu_baseline = True
+    scene = srt.host.Scene(scene_file)
+    if scene.error:
+        sys.exit("scene: " + scene.error)
     objs, n_obj = scene.objects_copy()
+    meshes, n_mesh = scene.meshes()
+    n_tri = sum(int(meshes[i].triangle_count) for i in range(n_mesh))
     n_sph = sum(1 for i in range(n_obj) if objs[i].type == srt.capi.OBJ_SPHERE)
     n_box = sum(1 for i in range(n_obj) if objs[i].type == srt.capi.OBJ_BOX)
 
     pt = srt.PathTracer(W, H, device=local_rank)
+    pt.set_meshes(meshes, n_mesh)
     pt.set_scene(objs, n_obj)
     pt.set_camera(srt.default_camera(FOV))
     # render straight into a torch tensor so the gather needs no staging copy
@@ -129,6 +148,7 @@ def main():
         # per-row cost probe: rays per memory row from a 1-spp pass (deterministic, same on all ranks)
         row_cost = []
         probe = srt.PathTracer(W, H, device=local_rank)
+        probe.set_meshes(meshes, n_mesh)
         probe.set_scene(objs, n_obj)
         probe.set_camera(srt.default_camera(FOV))
         band = 8
@@ -208,6 +228,7 @@ def main():
 
             gathered = (host_frame if rehearsal else frame.cpu()).numpy().view(np.uint32)
             chk = srt.PathTracer(W, H, device=local_rank)
+            chk.set_meshes(meshes, n_mesh)
             chk.set_scene(objs, n_obj)
             chk.set_camera(srt.default_camera(FOV))
             chk.render(spp=spp, bounces=args.bounces, seed=SEED)
@@ -246,7 +267,7 @@ def main():
             "config": {
                 "workload": "%s.json %dx%d, %d spp (%d per GPU-share), %d bounces, FOV %d, camera at origin" %
                             (args.scene, W, H, spp, args.spp, args.bounces, FOV),
-                "objects": {"spheres": n_sph, "boxes": n_box},
+                "objects": {"spheres": n_sph, "boxes": n_box, "mesh_triangles": n_tri},
                 "partition": "single frame" if world == 1 else "row stripes in memory-row space, %s split, one RCCL gather" % args.balance,
                 "bands": bands,
                 "rays_per_sample": rbar,

@@ -412,9 +412,13 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                                     }
                                 }
                             }
-                        } else {  // inner node: left child is node + 1, right child goes on the stack
-                            stack[sp++] = __float_as_int(n0.w);
-                            node = node + 1;
+                        } else {  // inner node: children are node + 1 (lower along the split axis) and n0.w
+                            const int axis = -cnt - 1;
+                            const float da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
+                            const int left = node + 1, right = __float_as_int(n0.w);
+                            const bool rev = da < 0.0f;  // front to back: the distance cull then prunes the far side
+                            stack[sp++] = rev ? left : right;
+                            node = rev ? right : left;
                             pop = false;
                         }
                     }

@@ -8,7 +8,7 @@
 //            (e2.xyz, bits(list index))               index) — restores the tie rule
 //   nodes: 2 float4 per node, depth-first order (left child = node + 1)
 //            (lo.xyz, bits(right child | first triangle))
-//            (hi.xyz, bits(0 = inner | triangle count of the leaf))
+//            (hi.xyz, bits(-(split axis + 1) for an inner node | triangle count of a leaf))
 // Build: median split of the centroids along the longest axis, leaves of <= 4 triangles —
 // deterministic and O(n log n).  Bounds are exact (float min/max of the float vertices); the
 // kernel pads them per ray (see closest_hit) so that the box filter is conservative with
@@ -91,7 +91,7 @@ inline void build_mesh_image(const srt_object* objects, size_t count, const std:
 
     struct Node {
         float lo[3], hi[3];
-        int32_t a, b;  // inner: a = right child, b = 0; leaf: a = first triangle, b = count
+        int32_t a, b;  // inner: a = right child, b = -(split axis + 1); leaf: a = first triangle, b = count
     };
     std::vector<Node> nodes;
     nodes.reserve(tris.size() / 2 + 16);
@@ -127,7 +127,7 @@ inline void build_mesh_image(const srt_object* objects, size_t count, const std:
                 });
                 build(nodes, tris, b, mid, depth + 1, max_depth);  // left = me + 1
                 nd.a = build(nodes, tris, mid, e, depth + 1, max_depth);
-                nd.b = 0;
+                nd.b = -(axis + 1);  // inner node: split axis, so the kernel can visit the near child first
             }
             nodes[me] = nd;
             return me;
