@@ -46,3 +46,40 @@ def test_frame_bit_exact(srt, oracle, name, w, h, spp, bounces):
                               spp=spp, bounces=bounces, seed=0, pow_mode=oracle.POW_LIBM)
     assert np.abs(_channels(fb) - _channels(lfb)).max() <= 1
     pt.close()
+
+
+@pytest.mark.parametrize("nsph,nbox", [(20, 0), (300, 3), (1500, 0)])
+def test_random_large_scenes(srt, oracle, nsph, nbox):
+    """Random scenes: few spheres (no clustering), hundreds (clusters of 4 plus boxes), 1500 (clusters
+    grow to K = 24; LDS image close to 100 KB).  Bit-exact vs the oracle."""
+    rng = np.random.default_rng(nsph)
+    objs = [dict(type=oracle.OBJ_SPHERE, position=(0, -1001, 5), radius=1000, base=(.8, .8, .8))]
+    for _ in range(nsph):
+        objs.append(dict(type=oracle.OBJ_SPHERE, position=(float(rng.uniform(-6, 6)), float(rng.uniform(-0.8, 3)), float(rng.uniform(3, 14))),
+                         radius=float(rng.uniform(0.05, 0.25)), base=tuple(float(v) for v in rng.uniform(0.2, 1, 3)),
+                         emissive=(2.0, 1.5, 1.0) if rng.uniform() < 0.05 else (0, 0, 0),
+                         specular_amount=float(rng.uniform(0, 1)), smoothness=float(rng.uniform(0, 1))))
+    for _ in range(nbox):
+        objs.insert(int(rng.integers(0, len(objs))), dict(type=oracle.OBJ_BOX, position=(float(rng.uniform(-4, 4)), float(rng.uniform(0, 2)), float(rng.uniform(5, 10))),
+                                                          half_size=tuple(float(v) for v in rng.uniform(0.2, 0.8, 3)), base=(.3, .6, .9)))
+    oarr, n = oracle.make_objects(objs)
+    w, h = 112, 63
+    pt = srt.PathTracer(w, h)
+    pt.set_scene(C.cast(oarr, C.POINTER(srt.Object)), n)
+    pt.set_camera(srt.default_camera())
+    pt.render(spp=2, bounces=5, seed=1, count_rays=True)
+    ofb, oacc, orays = oracle.render(oarr, n, oracle.default_environment(), oracle.default_camera(), w, h, spp=2, bounces=5, seed=1)
+    assert pt.stats().rays == orays
+    assert np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32))
+    assert np.array_equal(pt.framebuffer(), ofb)
+    pt.close()
+
+
+def test_scene_too_large_for_lds_is_rejected(srt, oracle):
+    objs = [dict(type=oracle.OBJ_SPHERE, position=(i * 0.01, 0, 5), radius=0.01) for i in range(4000)]
+    oarr, n = oracle.make_objects(objs)
+    pt = srt.PathTracer(16, 16)
+    with pytest.raises(srt.SrtError) as e:
+        pt.set_scene(C.cast(oarr, C.POINTER(srt.Object)), n)
+    assert e.value.code == srt.capi.ERR_INVALID_ARG and "LDS" in str(e.value)
+    pt.close()
