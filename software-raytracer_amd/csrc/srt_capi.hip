@@ -365,7 +365,7 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
     K.bvh_nodes = ctx->d_bvh_nodes;
     K.bvh_tris = ctx->d_bvh_tris;
     K.n_tris = ctx->mesh_image.n_tris;
-    for (int i = 0; i < 3; ++i) K.mesh_center[i] = ctx->mesh_image.center[i];
+    for (int i = 0; i < 3; ++i) K.mesh_center[i] = ctx->mesh_image.center[i], K.mesh_half[i] = ctx->mesh_image.half[i];
     K.mesh_r1 = ctx->mesh_image.half[0] + ctx->mesh_image.half[1] + ctx->mesh_image.half[2];
     K.accumulator = ctx->d_acc;
     K.framebuffer = ctx->d_fb;
@@ -405,8 +405,12 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     dim3 block(srt::WG_THREADS);
     SRT_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     // variants are a development aid for in-process A/B timing; all are bit-identical
-    if (K.n_tris > 0)  // EXTENSION: scenes with triangle meshes use the BVH-enabled instantiation
+    if (K.n_tris > 0 && use == 5)
         hipLaunchKernelGGL((srt::pathtrace_kernel<4, true>), grid, block, lds_bytes, ctx->stream, K);
+    else if (K.n_tris > 0 && use == 6)
+        hipLaunchKernelGGL((srt::pathtrace_kernel<2, true>), grid, block, lds_bytes, ctx->stream, K);
+    else if (K.n_tris > 0)  // EXTENSION: scenes with triangle meshes use the BVH-enabled instantiation
+        hipLaunchKernelGGL((srt::pathtrace_kernel<3, true>), grid, block, lds_bytes, ctx->stream, K);
     else if (use == 1)
         hipLaunchKernelGGL((srt::pathtrace_kernel<5, false>), grid, block, lds_bytes, ctx->stream, K);
     else if (use == 3)

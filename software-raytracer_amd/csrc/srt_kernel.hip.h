@@ -64,7 +64,8 @@ struct KernelParams {
     const float4* bvh_tris;
     int32_t n_tris;
     float mesh_center[3];
-    float mesh_r1;  // L1 half extent of the root box
+    float mesh_half[3];  // root box half extents
+    float mesh_r1;       // their sum
     float4* accumulator;
     uint32_t* framebuffer;
     unsigned long long* ray_counter;
@@ -363,70 +364,94 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             const V3 inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
             int stack[28];
             int sp = 0, node = 0;
-            bool go = active;
+            // root box (kernel argument, no memory access): most rays never come near the mesh, and
+            // when no lane of the wave does, the whole phase is skipped
+            bool go;
+            {
+                float t1x = ((P.mesh_center[0] - P.mesh_half[0] - pad) - o.x) * inv.x, t2x = ((P.mesh_center[0] + P.mesh_half[0] + pad) - o.x) * inv.x;
+                float t1y = ((P.mesh_center[1] - P.mesh_half[1] - pad) - o.y) * inv.y, t2y = ((P.mesh_center[1] + P.mesh_half[1] + pad) - o.y) * inv.y;
+                float t1z = ((P.mesh_center[2] - P.mesh_half[2] - pad) - o.z) * inv.z, t2z = ((P.mesh_center[2] + P.mesh_half[2] + pad) - o.z) * inv.z;
+                float tmin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+                float tmax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+                go = active && tmin <= tmax * 1.00001f + 1e-6f && tmax >= 0.0f && tmin <= 10001.0f && tmin * 0.9999f - 1e-5f <= best;
+            }
+            // exact test of the (up to 4) triangles of a leaf; ref = -(1 + first*4 + (count-1))
+            auto leaf = [&](int ref) {
+                const int v = -ref - 1, first = v >> 2, cnt = (v & 3) + 1;
+                for (int k = 0; k < 4; ++k) {
+                    if (k < cnt) {
+                        const float4 a = P.bvh_tris[3 * (first + k)], b = P.bvh_tris[3 * (first + k) + 1], c = P.bvh_tris[3 * (first + k) + 2];
+                        // Moller-Trumbore, binary32, no FMA, fixed order (the oracle's triangle_raytrace)
+                        V3 pv = v3(d.y * c.z - d.z * c.y, d.z * c.x - d.x * c.z, d.x * c.y - d.y * c.x);
+                        float det = (b.x * pv.x + b.y * pv.y) + b.z * pv.z;
+                        float idet = 1.0f / det;
+                        V3 tv = v3(o.x - a.x, o.y - a.y, o.z - a.z);
+                        float u = ((tv.x * pv.x + tv.y * pv.y) + tv.z * pv.z) * idet;
+                        V3 qv = v3(tv.y * b.z - tv.z * b.y, tv.z * b.x - tv.x * b.z, tv.x * b.y - tv.y * b.x);
+                        float vv = ((d.x * qv.x + d.y * qv.y) + d.z * qv.z) * idet;
+                        float t = ((c.x * qv.x + c.y * qv.y) + c.z * qv.z) * idet;
+                        const bool ok = (fabsf(det) >= 1e-12f) & (u >= 0.0f) & (u <= 1.0f) & (vv >= 0.0f) & (u + vv <= 1.0f) &
+                                        (t >= (float)0.01) & (t <= 10000.0f);
+                        const int ord = __float_as_int(c.w), gid = __float_as_int(b.w);
+                        // (distance, list index, triangle id) lexicographic minimum.  Written as
+                        // branch-free boolean algebra + selects on purpose: hipcc (ROCm 7.2) lowers the
+                        // nested short-circuit form of this update into exec-mask code that loses one of
+                        // the state updates for lanes winning through the tie term (seen in the ISA).
+                        const bool win = ok & ((t < best) | ((t == best) & ((ord < bord) | ((ord == bord) & (gid < bgid)))));
+                        best = win ? t : best;
+                        bp = win ? __float_as_int(a.w) : bp;
+                        btri = win ? first + k : btri;
+                        bgid = win ? gid : bgid;
+                        bord = win ? ord : bord;
+                    }
+                }
+            };
+            // entry distance of the ray into a padded box, +inf when it misses (NaN-suppressing
+            // min/max: v_min/v_max return the non-NaN operand)
+            auto entry = [&](float lx, float ly, float lz, float hx, float hy, float hz) {
+                float t1x = ((lx - pad) - o.x) * inv.x, t2x = ((hx + pad) - o.x) * inv.x;
+                float t1y = ((ly - pad) - o.y) * inv.y, t2y = ((hy + pad) - o.y) * inv.y;
+                float t1z = ((lz - pad) - o.z) * inv.z, t2z = ((hz + pad) - o.z) * inv.z;
+                float tmin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+                float tmax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+                const bool hit = tmin <= tmax * 1.00001f + 1e-6f && tmax >= 0.0f && tmin <= 10001.0f;
+                return hit ? tmin : __builtin_inff();
+            };
             while (__builtin_amdgcn_ballot_w64(go) != 0ull) {
                 if (go) {
-                    const float4 n0 = P.bvh_nodes[2 * node], n1 = P.bvh_nodes[2 * node + 1];
-                    // NaN-suppressing slab test (v_min/v_max return the non-NaN operand)
-                    float t1x = ((n0.x - pad) - o.x) * inv.x, t2x = ((n1.x + pad) - o.x) * inv.x;
-                    float t1y = ((n0.y - pad) - o.y) * inv.y, t2y = ((n1.y + pad) - o.y) * inv.y;
-                    float t1z = ((n0.z - pad) - o.z) * inv.z, t2z = ((n1.z + pad) - o.z) * inv.z;
-                    float tmin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
-                    float tmax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
-                    const bool boxhit = tmin <= tmax * 1.00001f + 1e-6f && tmax >= 0.0f && tmin * 0.9999f - 1e-5f <= best && tmin <= 10001.0f;
-                    const int cnt = __float_as_int(n1.w);
-                    bool pop = true;
-                    if (boxhit) {
-                        if (cnt > 0) {  // leaf: up to 4 triangles
-                            const int first = __float_as_int(n0.w);
-                            for (int k = 0; k < 4; ++k) {
-                                if (k < cnt) {
-                                    const float4 a = P.bvh_tris[3 * (first + k)], b = P.bvh_tris[3 * (first + k) + 1], c = P.bvh_tris[3 * (first + k) + 2];
-                                    // Moller-Trumbore, binary32, no FMA, fixed order (the oracle's triangle_raytrace)
-                                    V3 pv = v3(d.y * c.z - d.z * c.y, d.z * c.x - d.x * c.z, d.x * c.y - d.y * c.x);
-                                    float det = (b.x * pv.x + b.y * pv.y) + b.z * pv.z;
-                                    if (fabsf(det) >= 1e-12f) {
-                                        float idet = 1.0f / det;
-                                        V3 tv = v3(o.x - a.x, o.y - a.y, o.z - a.z);
-                                        float u = ((tv.x * pv.x + tv.y * pv.y) + tv.z * pv.z) * idet;
-                                        if (u >= 0.0f && u <= 1.0f) {
-                                            V3 qv = v3(tv.y * b.z - tv.z * b.y, tv.z * b.x - tv.x * b.z, tv.x * b.y - tv.y * b.x);
-                                            float vv = ((d.x * qv.x + d.y * qv.y) + d.z * qv.z) * idet;
-                                            if (vv >= 0.0f && u + vv <= 1.0f) {
-                                                float t = ((c.x * qv.x + c.y * qv.y) + c.z * qv.z) * idet;
-                                                if (t >= (float)0.01 && t <= 10000.0f) {
-                                                    const int ord = __float_as_int(c.w), gid = __float_as_int(b.w);
-                                                    // (distance, list index, triangle id) lexicographic minimum.  Written as
-                                                    // branch-free boolean algebra + selects on purpose: hipcc (ROCm 7.2) lowers the
-                                                    // nested short-circuit form of this update into exec-mask code that loses one of
-                                                    // the state updates for lanes winning through the tie term (seen in the ISA).
-                                                    const bool win = (t < best) | ((t == best) & ((ord < bord) | ((ord == bord) & (gid < bgid))));
-                                                    best = win ? t : best;
-                                                    bp = win ? __float_as_int(a.w) : bp;
-                                                    btri = win ? first + k : btri;
-                                                    bgid = win ? gid : bgid;
-                                                    bord = win ? ord : bord;
-                                                }
-                                            }
-                                        }
-                                    }
-                                }
-                            }
-                        } else {  // inner node: children are node + 1 (lower along the split axis) and n0.w
-                            const int axis = -cnt - 1;
-                            const float da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
-                            const int left = node + 1, right = __float_as_int(n0.w);
-                            const bool rev = da < 0.0f;  // front to back: the distance cull then prunes the far side
-                            stack[sp++] = rev ? left : right;
-                            node = rev ? right : left;
-                            pop = false;
-                        }
+                    const float4 n0 = P.bvh_nodes[4 * node], n1 = P.bvh_nodes[4 * node + 1], n2 = P.bvh_nodes[4 * node + 2],
+                                 n3 = P.bvh_nodes[4 * node + 3];
+                    float tl = entry(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y);
+                    float tr = entry(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w);
+                    int rl = __float_as_int(n3.x), rr = __float_as_int(n3.y);
+                    if (tr < tl) {  // near child first
+                        float tt = tl;
+                        tl = tr;
+                        tr = tt;
+                        int rt = rl;
+                        rl = rr;
+                        rr = rt;
                     }
-                    if (pop) {
-                        if (sp == 0)
-                            go = false;
-                        else
-                            node = stack[--sp];
+                    // a child is entered only if a triangle inside could still beat `best`
+                    bool vl = tl < __builtin_inff() && tl * 0.9999f - 1e-5f <= best;
+                    if (vl && rl < 0) {  // near leaf: test now, so the far child sees the new best
+                        leaf(rl);
+                        vl = false;
+                    }
+                    bool vr = tr < __builtin_inff() && tr * 0.9999f - 1e-5f <= best;
+                    if (vr && rr < 0) {
+                        leaf(rr);
+                        vr = false;
+                    }
+                    if (vl) {  // inner children: descend into the near one, stack the far one
+                        if (vr) stack[sp++] = rr;
+                        node = rl;
+                    } else if (vr) {
+                        node = rr;
+                    } else if (sp > 0) {
+                        node = stack[--sp];
+                    } else {
+                        go = false;
                     }
                 }
             }

@@ -6,11 +6,14 @@
 //            (v0.xyz, bits(primitive id p))      p indexes the LDS material table
 //            (e1.xyz, bits(global triangle id))  id = position in (object list order, triangle
 //            (e2.xyz, bits(list index))               index) — restores the tie rule
-//   nodes: 2 float4 per node, depth-first order (left child = node + 1)
-//            (lo.xyz, bits(right child | first triangle))
-//            (hi.xyz, bits(-(split axis + 1) for an inner node | triangle count of a leaf))
-// Build: median split of the centroids along the longest axis, leaves of <= 4 triangles —
-// deterministic and O(n log n).  Bounds are exact (float min/max of the float vertices); the
+//   nodes: 4 float4 per INNER node holding BOTH children's boxes, so one 64-byte load per level:
+//            (L.lo.x, L.lo.y, L.lo.z, L.hi.x) (L.hi.y, L.hi.z, R.lo.x, R.lo.y)
+//            (R.lo.z, R.hi.x, R.hi.y, R.hi.z) (bits(left ref), bits(right ref), _, _)
+//          child ref >= 0: inner node index; ref < 0: leaf, -(1 + first*4 + (count-1));
+//          an absent child has an inverted box (lo = +inf, hi = -inf) and is never entered.
+//          Node 0 is the root; a mesh of <= 4 triangles is a root with one leaf child.
+// Build: binned surface-area heuristic (16 bins per axis, median fallback), leaves of <= 4
+// triangles — deterministic.  Bounds are exact (float min/max of the float vertices); the
 // kernel pads them per ray (see closest_hit) so that the box filter is conservative with
 // respect to the rounding of the triangle test.
 #pragma once
@@ -118,16 +121,79 @@ inline void build_mesh_image(const srt_object* objects, size_t count, const std:
                 nd.a = b;
                 nd.b = e - b;
             } else {
-                int axis = 0;
-                if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
-                if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
-                const int mid = (b + e) / 2;
-                std::nth_element(tris.begin() + b, tris.begin() + mid, tris.begin() + e, [axis](const Tri& x, const Tri& y) {
-                    return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.gid < y.gid);
-                });
+                // binned surface-area heuristic (16 bins per axis); falls back to the median of the
+                // longest axis when no split is cheaper (leaves must not exceed 4 triangles)
+                auto area = [](const float* lo, const float* hi) {
+                    double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+                    return dx < 0 ? 0.0 : 2.0 * (dx * dy + dy * dz + dz * dx);
+                };
+                constexpr int NB = 16;
+                int best_axis = -1, best_bin = -1;
+                double best_cost = 1e300;
+                for (int ax = 0; ax < 3; ++ax) {
+                    const double ext = (double)chi[ax] - clo[ax];
+                    if (!(ext > 0)) continue;
+                    float blo[NB][3], bhi[NB][3];
+                    int bcnt[NB];
+                    for (int q = 0; q < NB; ++q) {
+                        bcnt[q] = 0;
+                        for (int a2 = 0; a2 < 3; ++a2) blo[q][a2] = INFINITY, bhi[q][a2] = -INFINITY;
+                    }
+                    for (int k = b; k < e; ++k) {
+                        int q = (int)(((double)tris[k].c[ax] - clo[ax]) / ext * NB);
+                        q = q < 0 ? 0 : (q >= NB ? NB - 1 : q);
+                        bcnt[q]++;
+                        for (int a2 = 0; a2 < 3; ++a2) {
+                            blo[q][a2] = std::min(blo[q][a2], tris[k].lo[a2]);
+                            bhi[q][a2] = std::max(bhi[q][a2], tris[k].hi[a2]);
+                        }
+                    }
+                    double rarea[NB];
+                    int rcnt[NB];
+                    {
+                        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                        int c = 0;
+                        for (int q = NB - 1; q >= 1; --q) {
+                            for (int a2 = 0; a2 < 3; ++a2) lo[a2] = std::min(lo[a2], blo[q][a2]), hi[a2] = std::max(hi[a2], bhi[q][a2]);
+                            c += bcnt[q];
+                            rarea[q] = area(lo, hi);
+                            rcnt[q] = c;
+                        }
+                    }
+                    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                    int c = 0;
+                    for (int q = 0; q < NB - 1; ++q) {  // split between bin q and q + 1
+                        for (int a2 = 0; a2 < 3; ++a2) lo[a2] = std::min(lo[a2], blo[q][a2]), hi[a2] = std::max(hi[a2], bhi[q][a2]);
+                        c += bcnt[q];
+                        if (c == 0 || rcnt[q + 1] == 0) continue;
+                        const double cost = area(lo, hi) * c + rarea[q + 1] * rcnt[q + 1];
+                        if (cost < best_cost) best_cost = cost, best_axis = ax, best_bin = q;
+                    }
+                }
+                int mid;
+                if (best_axis >= 0) {
+                    const int ax = best_axis;
+                    const double ext = (double)chi[ax] - clo[ax], lo0 = clo[ax];
+                    const int bin = best_bin;
+                    auto it = std::stable_partition(tris.begin() + b, tris.begin() + e, [=](const Tri& x) {
+                        int q = (int)(((double)x.c[ax] - lo0) / ext * NB);
+                        q = q < 0 ? 0 : (q >= NB ? NB - 1 : q);
+                        return q <= bin;
+                    });
+                    mid = (int)(it - tris.begin());
+                }
+                if (best_axis < 0 || mid == b || mid == e) {  // degenerate: median of the longest axis
+                    int axis = 0;
+                    if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
+                    if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
+                    mid = (b + e) / 2;
+                    std::nth_element(tris.begin() + b, tris.begin() + mid, tris.begin() + e, [axis](const Tri& x, const Tri& y) {
+                        return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.gid < y.gid);
+                    });
+                }
                 build(nodes, tris, b, mid, depth + 1, max_depth);  // left = me + 1
                 nd.a = build(nodes, tris, mid, e, depth + 1, max_depth);
-                nd.b = -(axis + 1);  // inner node: split axis, so the kernel can visit the near child first
+                nd.b = 0;
             }
             nodes[me] = nd;
             return me;
@@ -136,11 +202,54 @@ inline void build_mesh_image(const srt_object* objects, size_t count, const std:
     out.max_depth = 0;
     Rec::build(nodes, tris, 0, (int)tris.size(), 1, out.max_depth);
 
-    out.n_nodes = (int)nodes.size();
-    out.nodes.resize(nodes.size() * 2);
-    for (size_t k = 0; k < nodes.size(); ++k) {
-        out.nodes[2 * k] = make_float4(nodes[k].lo[0], nodes[k].lo[1], nodes[k].lo[2], bits_of(nodes[k].a));
-        out.nodes[2 * k + 1] = make_float4(nodes[k].hi[0], nodes[k].hi[1], nodes[k].hi[2], bits_of(nodes[k].b));
+    // second pass: inner nodes that carry both children's boxes
+    struct Wide {
+        float box[2][6];
+        int32_t ref[2];
+    };
+    std::vector<Wide> wide;
+    std::vector<int> wide_index(nodes.size(), -1);
+    for (size_t k = 0; k < nodes.size(); ++k)
+        if (nodes[k].b <= 0) {  // inner
+            wide_index[k] = (int)wide.size();
+            wide.push_back(Wide());
+        }
+    auto ref_of = [&](int node) -> int32_t {
+        if (nodes[node].b > 0) return -(1 + nodes[node].a * 4 + (nodes[node].b - 1));
+        return wide_index[node];
+    };
+    auto put_box = [&](float* dst, int node) {
+        for (int ax = 0; ax < 3; ++ax) {
+            dst[ax] = nodes[node].lo[ax];
+            dst[3 + ax] = nodes[node].hi[ax];
+        }
+    };
+    if (wide.empty()) {  // the whole mesh is one leaf
+        Wide w;
+        put_box(w.box[0], 0);
+        for (int q = 0; q < 3; ++q) w.box[1][q] = INFINITY, w.box[1][3 + q] = -INFINITY;
+        w.ref[0] = ref_of(0);
+        w.ref[1] = -1;
+        wide.push_back(w);
+    } else {
+        for (size_t k = 0; k < nodes.size(); ++k) {
+            if (nodes[k].b > 0) continue;
+            Wide& w = wide[(size_t)wide_index[k]];
+            const int left = (int)k + 1, right = nodes[k].a;
+            put_box(w.box[0], left);
+            put_box(w.box[1], right);
+            w.ref[0] = ref_of(left);
+            w.ref[1] = ref_of(right);
+        }
+    }
+    out.n_nodes = (int)wide.size();
+    out.nodes.resize(wide.size() * 4);
+    for (size_t k = 0; k < wide.size(); ++k) {
+        const Wide& w = wide[k];
+        out.nodes[4 * k] = make_float4(w.box[0][0], w.box[0][1], w.box[0][2], w.box[0][3]);
+        out.nodes[4 * k + 1] = make_float4(w.box[0][4], w.box[0][5], w.box[1][0], w.box[1][1]);
+        out.nodes[4 * k + 2] = make_float4(w.box[1][2], w.box[1][3], w.box[1][4], w.box[1][5]);
+        out.nodes[4 * k + 3] = make_float4(bits_of(w.ref[0]), bits_of(w.ref[1]), 0.0f, 0.0f);
     }
     out.tris.resize(tris.size() * 3);
     for (size_t k = 0; k < tris.size(); ++k) {
@@ -150,7 +259,9 @@ inline void build_mesh_image(const srt_object* objects, size_t count, const std:
     }
     for (int ax = 0; ax < 3; ++ax) {
         out.center[ax] = 0.5f * (nodes[0].lo[ax] + nodes[0].hi[ax]);
-        out.half[ax] = 0.5f * (nodes[0].hi[ax] - nodes[0].lo[ax]);
+        // half extent rounded up so that [center - half, center + half] contains the root box
+        float h = std::max(nodes[0].hi[ax] - out.center[ax], out.center[ax] - nodes[0].lo[ax]);
+        out.half[ax] = nextafterf(h * 1.000001f, INFINITY);
     }
 }
 

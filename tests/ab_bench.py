@@ -18,13 +18,22 @@ ap.add_argument("--spp", type=int, default=32)
 ap.add_argument("--bounces", type=int, default=8)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--mesh", type=int, default=0)
 a = ap.parse_args()
 srt = importlib.import_module("software-raytracer_amd")
 L = srt.load_library()
 L.srt_debug_set_variant.argtypes = [C.c_void_p, C.c_int]
-sc = srt.host.Scene(os.path.join(ROOT, "software-raytracer_amd", "scenes", a.scene + ".json"))
+path = os.path.join(ROOT, "software-raytracer_amd", "scenes", a.scene + ".json")
+if a.mesh:
+    import json, tempfile
+    sj = json.load(open(path))
+    sj["SceneObjects"][64]["Renderer"] = {"Type": "Mesh", "Primitive": "UVSphere", "Radius": 1.0, "Stacks": a.mesh, "Slices": a.mesh}
+    tmp = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False); json.dump(sj, tmp); tmp.close(); path = tmp.name
+sc = srt.host.Scene(path)
 objs, n = sc.objects_copy()
+meshes, nm = sc.meshes()
 pt = srt.PathTracer(a.width, a.height)
+pt.set_meshes(meshes, nm)
 pt.set_scene(objs, n)
 pt.set_camera(srt.default_camera())
 variants = [int(v) for v in a.variants.split(",")]
