@@ -59,6 +59,7 @@ struct srt_context {
     srt::MeshImage mesh_image;
     float4* d_bvh_nodes = nullptr;
     float4* d_bvh_tris = nullptr;
+    int32_t* d_bvh_gidpos = nullptr;
 
     srt_environment env;
     HostCamera camera;
@@ -191,6 +192,7 @@ int srt_destroy(srt_context* ctx) {
     if (ctx->d_rays) (void)hipFree(ctx->d_rays);
     if (ctx->d_bvh_nodes) (void)hipFree(ctx->d_bvh_nodes);
     if (ctx->d_bvh_tris) (void)hipFree(ctx->d_bvh_tris);
+    if (ctx->d_bvh_gidpos) (void)hipFree(ctx->d_bvh_gidpos);
     if (ctx->d_pick) (void)hipFree(ctx->d_pick);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
@@ -220,7 +222,8 @@ int srt_set_scene(srt_context* ctx, const srt_object* objects, size_t count) {
     for (int v = 0; v < 2; ++v) {
         // with meshes both images are the same one, so that primitive ids agree with the BVH
         srt::SceneLayout L = srt::build_scene_image(objects, count, (v == 0 || has_mesh) && !no_cluster, ctx->h_scene[v]);
-        if ((size_t)L.total_vec4 * sizeof(float4) + srt::WG_SCRATCH_BYTES > (size_t)ctx->lds_limit_bytes || count >= 32768)
+        if ((size_t)L.total_vec4 * sizeof(float4) + srt::WG_SCRATCH_BYTES + (has_mesh ? srt::WG_MESH_SCRATCH_BYTES : 0) > (size_t)ctx->lds_limit_bytes ||
+            count >= 32768)
             return fail(ctx, SRT_ERR_INVALID_ARG,
                         "srt_set_scene: %d spheres + %d boxes need %zu B of LDS, limit %d B (tile streaming not built yet)",
                         L.n_spheres, L.nb, (size_t)L.total_vec4 * sizeof(float4), ctx->lds_limit_bytes);
@@ -238,7 +241,9 @@ int srt_set_scene(srt_context* ctx, const srt_object* objects, size_t count) {
     srt::build_mesh_image(objects, count, ctx->meshes, ctx->layout[0].nsT + ctx->layout[0].nb, ctx->mesh_image);
     if (ctx->d_bvh_nodes) SRT_HIP(ctx, hipFree(ctx->d_bvh_nodes));
     if (ctx->d_bvh_tris) SRT_HIP(ctx, hipFree(ctx->d_bvh_tris));
+    if (ctx->d_bvh_gidpos) SRT_HIP(ctx, hipFree(ctx->d_bvh_gidpos));
     ctx->d_bvh_nodes = ctx->d_bvh_tris = nullptr;
+    ctx->d_bvh_gidpos = nullptr;
     if (ctx->mesh_image.n_tris > 0) {
         if (ctx->mesh_image.max_depth > 26) return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: BVH too deep (%d)", ctx->mesh_image.max_depth);
         SRT_HIP(ctx, hipMalloc((void**)&ctx->d_bvh_nodes, ctx->mesh_image.nodes.size() * sizeof(float4)));
@@ -247,6 +252,11 @@ int srt_set_scene(srt_context* ctx, const srt_object* objects, size_t count) {
                                     hipMemcpyHostToDevice, ctx->stream));
         SRT_HIP(ctx, hipMemcpyAsync(ctx->d_bvh_tris, ctx->mesh_image.tris.data(), ctx->mesh_image.tris.size() * sizeof(float4),
                                     hipMemcpyHostToDevice, ctx->stream));
+        SRT_HIP(ctx, hipMalloc((void**)&ctx->d_bvh_gidpos, ctx->mesh_image.gidpos.size() * sizeof(int32_t)));
+        SRT_HIP(ctx, hipMemcpyAsync(ctx->d_bvh_gidpos, ctx->mesh_image.gidpos.data(), ctx->mesh_image.gidpos.size() * sizeof(int32_t),
+                                    hipMemcpyHostToDevice, ctx->stream));
+        if (ctx->mesh_image.n_nodes >= (1 << 26) || ctx->mesh_image.n_tris >= (1 << 24))
+            return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: mesh too large (%d triangles)", ctx->mesh_image.n_tris);
     }
     ctx->scene_set = true;
     return SRT_OK;
@@ -364,6 +374,7 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
     K.scene = ctx->d_scene[img];
     K.bvh_nodes = ctx->d_bvh_nodes;
     K.bvh_tris = ctx->d_bvh_tris;
+    K.bvh_gidpos = ctx->d_bvh_gidpos;
     K.n_tris = ctx->mesh_image.n_tris;
     for (int i = 0; i < 3; ++i) K.mesh_center[i] = ctx->mesh_image.center[i], K.mesh_half[i] = ctx->mesh_image.half[i];
     K.mesh_r1 = ctx->mesh_image.half[0] + ctx->mesh_image.half[1] + ctx->mesh_image.half[2];
@@ -371,7 +382,8 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
     K.framebuffer = ctx->d_fb;
     K.ray_counter = ctx->d_rays;
 
-    lds_bytes = (size_t)(SL.total_vec4 > 0 ? SL.total_vec4 : 1) * sizeof(float4) + srt::WG_SCRATCH_BYTES;
+    lds_bytes = (size_t)(SL.total_vec4 > 0 ? SL.total_vec4 : 1) * sizeof(float4) + srt::WG_SCRATCH_BYTES +
+                (ctx->mesh_image.n_tris > 0 ? srt::WG_MESH_SCRATCH_BYTES : 0);
     return SRT_OK;
 }
 

@@ -62,6 +62,7 @@ struct KernelParams {
     // EXTENSION: triangle meshes (srt_mesh_bvh.h); n_tris == 0 -> none
     const float4* bvh_nodes;
     const float4* bvh_tris;
+    const int32_t* bvh_gidpos;  // global triangle id -> position in bvh_tris
     int32_t n_tris;
     float mesh_center[3];
     float mesh_half[3];  // root box half extents
@@ -82,6 +83,10 @@ constexpr int RING_DEPTH = 4;  // ring entries per slot when all 64 pixels of th
 // per-wave: 64 result slots (8 B) | work list (2 B) | 64 pixel records (48 B) | ring (16 B)
 constexpr int WAVE_SCRATCH_BYTES = 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4 + 64 * RING_DEPTH * 16;
 constexpr int WG_SCRATCH_BYTES = WAVE_SCRATCH_BYTES * WG_TILES_X * WG_TILES_Y;
+// extra per-wave LDS of the mesh kernel: node LIFO + leaf queue of the cooperative BVH traversal
+constexpr int MESH_QN = 1024, MESH_QL = 512;
+constexpr int MESH_WAVE_BYTES = (MESH_QN + MESH_QL) * 4;
+constexpr int WG_MESH_SCRATCH_BYTES = MESH_WAVE_BYTES * WG_TILES_X * WG_TILES_Y;
 
 __device__ __forceinline__ float clamp0(float v) { return v < 0 ? 0.0f : v; }  // Common.hpp:254-257
 
@@ -114,6 +119,7 @@ struct Lds {
     unsigned short* work;     // this wave's work list
     float* pix;               // this wave's 64 pixel records (12 floats each)
     float4* ring;             // this wave's sample-colour ring
+    unsigned* meshq;          // mesh kernel only: node LIFO [MESH_QN] then leaf queue [MESH_QL]
     __device__ __forceinline__ float4 sphere(int p) const { return v[p]; }
     __device__ __forceinline__ float4 bound(int k) const { return v[off_bounds + k]; }
     __device__ __forceinline__ float4 box_c(int j) const { return v[off_box + 2 * j]; }
@@ -417,6 +423,123 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                 const bool hit = tmin <= tmax * 1.00001f + 1e-6f && tmax >= 0.0f && tmin <= 10001.0f;
                 return hit ? tmin : __builtin_inff();
             };
+            // ---- wave-cooperative traversal.  Rays that come near the mesh put (ray lane, node) items on
+            // a LIFO in LDS; every round all 64 lanes pop items, fetch the item's ray with __shfl, test
+            // the node's two child boxes and push the survivors with ballot prefix sums (far child first,
+            // so the near one is popped first).  Leaves go to a second queue and are tested 64 at a
+            // time.  A ray's best triangle is merged through a 64-bit LDS atomicMin on
+            // (ordered t || global triangle id) — the id order is (list order of the object, triangle
+            // index), i.e. the tie rule — and doubles as the culling distance.  If a queue would
+            // overflow, the exact per-lane traversal below redoes the phase from scratch.
+            bool overflow = false;
+            if (__builtin_amdgcn_ballot_w64(go) != 0ull) {
+                const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                unsigned* qn = S.meshq;
+                unsigned* ql = S.meshq + MESH_QN;
+                int nN = 0, nL = 0;
+                auto okey = [](float t) {  // order-preserving float -> uint
+                    unsigned u = __float_as_uint(t + 0.0f);
+                    return u ^ ((u & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);
+                };
+                auto unkey = [](unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u); };
+                auto push = [&](bool pred, unsigned item, unsigned* q, int& n, int cap) {
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
+                    const int cnt = __builtin_popcountll(m);
+                    if (n + cnt > cap) {
+                        overflow = true;
+                    } else {
+                        if (pred) q[n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = item;
+                        n += cnt;
+                    }
+                };
+                S.res[lane] = ((unsigned long long)okey(best) << 32) | 0xFFFFFFFFull;  // no triangle yet
+                push(go, (unsigned)lane << 26, qn, nN, MESH_QN);
+                __builtin_amdgcn_wave_barrier();
+                while (!overflow && (nN > 0 || nL > 0)) {
+                    const bool node_round = nN > 0 && nL <= MESH_QL - 128;
+                    int& n = node_round ? nN : nL;
+                    const int take = n < 64 ? n : 64;
+                    n -= take;
+                    const bool on = lane < take;
+                    const unsigned item = on ? (node_round ? qn : ql)[n + lane] : ((unsigned)lane << 26);
+                    const int src = (int)(item >> 26), code = (int)(item & 0x3FFFFFFu);
+                    const V3 ro = v3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
+                    const V3 rd = v3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
+                    const float rpad = __shfl(pad, src);
+                    __builtin_amdgcn_wave_barrier();
+                    if (node_round) {
+                        const V3 rinv = v3(__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z));
+                        const float thr = unkey((unsigned)(S.res[src] >> 32));
+                        const float4 n0 = P.bvh_nodes[4 * code], n1 = P.bvh_nodes[4 * code + 1], n2 = P.bvh_nodes[4 * code + 2],
+                                     n3 = P.bvh_nodes[4 * code + 3];
+                        auto entry2 = [&](float lx, float ly, float lz, float hx, float hy, float hz) {
+                            float t1x = ((lx - rpad) - ro.x) * rinv.x, t2x = ((hx + rpad) - ro.x) * rinv.x;
+                            float t1y = ((ly - rpad) - ro.y) * rinv.y, t2y = ((hy + rpad) - ro.y) * rinv.y;
+                            float t1z = ((lz - rpad) - ro.z) * rinv.z, t2z = ((hz + rpad) - ro.z) * rinv.z;
+                            float tmin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+                            float tmax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+                            const bool hit = tmin <= tmax * 1.00001f + 1e-6f && tmax >= 0.0f && tmin <= 10001.0f;
+                            return hit ? tmin : __builtin_inff();
+                        };
+                        float tl = entry2(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y);
+                        float tr = entry2(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w);
+                        int rl = __float_as_int(n3.x), rr = __float_as_int(n3.y);
+                        const bool swap = tr < tl;
+                        const float tnear = swap ? tr : tl, tfar = swap ? tl : tr;
+                        const int rnear = swap ? rr : rl, rfar = swap ? rl : rr;
+                        const bool vn = on & (tnear < __builtin_inff()) & (tnear * 0.9999f - 1e-5f <= thr);
+                        const bool vf = on & (tfar < __builtin_inff()) & (tfar * 0.9999f - 1e-5f <= thr);
+                        const unsigned tag = (unsigned)src << 26;
+                        push(vf & (rfar >= 0), tag | (unsigned)rfar, qn, nN, MESH_QN);
+                        push(vn & (rnear >= 0), tag | (unsigned)rnear, qn, nN, MESH_QN);
+                        push(vf & (rfar < 0), tag | (unsigned)(-rfar - 1), ql, nL, MESH_QL);
+                        push(vn & (rnear < 0), tag | (unsigned)(-rnear - 1), ql, nL, MESH_QL);
+                    } else {
+                        const int first = code >> 2, cnt = (code & 3) + 1;
+                        float tb = __builtin_inff();
+                        int gb = 0x7fffffff;
+                        for (int k = 0; k < 4; ++k) {
+                            const int q = first + (k < cnt ? k : 0);
+                            const float4 a = P.bvh_tris[3 * q], b = P.bvh_tris[3 * q + 1], c = P.bvh_tris[3 * q + 2];
+                            // Moller-Trumbore, binary32, no FMA, fixed order (the oracle's triangle_raytrace)
+                            V3 pv = v3(rd.y * c.z - rd.z * c.y, rd.z * c.x - rd.x * c.z, rd.x * c.y - rd.y * c.x);
+                            float det = (b.x * pv.x + b.y * pv.y) + b.z * pv.z;
+                            float idet = 1.0f / det;
+                            V3 tv = v3(ro.x - a.x, ro.y - a.y, ro.z - a.z);
+                            float u = ((tv.x * pv.x + tv.y * pv.y) + tv.z * pv.z) * idet;
+                            V3 qv = v3(tv.y * b.z - tv.z * b.y, tv.z * b.x - tv.x * b.z, tv.x * b.y - tv.y * b.x);
+                            float vv = ((rd.x * qv.x + rd.y * qv.y) + rd.z * qv.z) * idet;
+                            float t = ((c.x * qv.x + c.y * qv.y) + c.z * qv.z) * idet;
+                            const bool ok = on & (k < cnt) & (fabsf(det) >= 1e-12f) & (u >= 0.0f) & (u <= 1.0f) & (vv >= 0.0f) & (u + vv <= 1.0f) &
+                                            (t >= (float)0.01) & (t <= 10000.0f);
+                            const int gid = __float_as_int(b.w);
+                            const bool win = ok & ((t < tb) | ((t == tb) & (gid < gb)));
+                            tb = win ? t : tb;
+                            gb = win ? gid : gb;
+                        }
+                        if (gb != 0x7fffffff) atomicMin(&S.res[src], ((unsigned long long)okey(tb) << 32) | (unsigned)gb);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (!overflow) {  // the ray's best triangle, if any, against the best analytic hit
+                    const unsigned long long r = S.res[lane];
+                    const unsigned gid = (unsigned)r;
+                    if (go && gid != 0xFFFFFFFFu) {
+                        const float tm = unkey((unsigned)(r >> 32));
+                        const int pos = P.bvh_gidpos[gid];
+                        const int ordm = __float_as_int(P.bvh_tris[3 * pos + 2].w);
+                        const bool win = (tm < best) | ((tm == best) & (ordm < bord));
+                        best = win ? tm : best;
+                        bp = win ? __float_as_int(P.bvh_tris[3 * pos].w) : bp;
+                        btri = win ? pos : btri;
+                        bgid = win ? (int)gid : bgid;
+                        bord = win ? ordm : bord;
+                    }
+                    go = false;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            // ---- exact per-lane traversal: the fallback when a queue overflowed
             while (__builtin_amdgcn_ballot_w64(go) != 0ull) {
                 if (go) {
                     const float4 n0 = P.bvh_nodes[4 * node], n1 = P.bvh_nodes[4 * node + 1], n2 = P.bvh_nodes[4 * node + 2],
@@ -529,7 +652,8 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     Lds S{lds_scene, P.nu4, P.nc, P.K, P.nsT, P.nb, P.off_bounds, P.off_box, P.off_mat,
           reinterpret_cast<unsigned long long*>(scratch), reinterpret_cast<unsigned short*>(scratch + 64 * 8),
           reinterpret_cast<float*>(scratch + 64 * 8 + WORK_MAX * 2),
-          reinterpret_cast<float4*>(scratch + 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4)};
+          reinterpret_cast<float4*>(scratch + 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4),
+          reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds_scene + P.scene_vec4) + WG_SCRATCH_BYTES + (threadIdx.x >> 6) * MESH_WAVE_BYTES)};
 
     // ---- pixel of this lane ----------------------------------------------------------
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -830,7 +954,8 @@ __global__ void __launch_bounds__(64) pick_kernel(const KernelParams P, int px, 
     Lds S{lds_scene, P.nu4, P.nc, P.K, P.nsT, P.nb, P.off_bounds, P.off_box, P.off_mat,
           reinterpret_cast<unsigned long long*>(scratch), reinterpret_cast<unsigned short*>(scratch + 64 * 8),
           reinterpret_cast<float*>(scratch + 64 * 8 + WORK_MAX * 2),
-          reinterpret_cast<float4*>(scratch + 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4)};
+          reinterpret_cast<float4*>(scratch + 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4),
+          reinterpret_cast<unsigned*>(scratch + WG_SCRATCH_BYTES)};
     float nX = ((float)px / (float)P.width) * 2 - 1;
     float nY = ((float)py / (float)P.height) * 2 - 1;
     V3 u = v3(P.right_rd[0] * nX, P.right_rd[1] * nX, P.right_rd[2] * nX);

@@ -37,6 +37,7 @@ struct HostMesh {
 
 struct MeshImage {
     std::vector<float4> tris, nodes;
+    std::vector<int32_t> gidpos;  // global triangle id -> position in `tris` (leaf order)
     int n_tris = 0, n_nodes = 0, n_mesh_objects = 0, max_depth = 0;
     float center[3] = {0, 0, 0}, half[3] = {0, 0, 0};  // root box
 };
@@ -252,6 +253,8 @@ inline void build_mesh_image(const srt_object* objects, size_t count, const std:
         out.nodes[4 * k + 3] = make_float4(bits_of(w.ref[0]), bits_of(w.ref[1]), 0.0f, 0.0f);
     }
     out.tris.resize(tris.size() * 3);
+    out.gidpos.assign(tris.size(), 0);
+    for (size_t k = 0; k < tris.size(); ++k) out.gidpos[(size_t)tris[k].gid] = (int32_t)k;
     for (size_t k = 0; k < tris.size(); ++k) {
         out.tris[3 * k] = make_float4(tris[k].v0[0], tris[k].v0[1], tris[k].v0[2], bits_of(tris[k].prim));
         out.tris[3 * k + 1] = make_float4(tris[k].e1[0], tris[k].e1[1], tris[k].e1[2], bits_of(tris[k].gid));
