@@ -339,7 +339,7 @@ def main():
             "unit": "path-samples/s",
             "cores": cores,
             "kind": "port",
-            "sample": "same scene/camera/seed at %dx%d, %d spp, %d bounces, row bands over %d threads (%.2f s)" %
+            "sample": "same scene/camera/seed at %dx%d, %d spp, %d bounces, rows interleaved over %d threads (%.2f s)" %
                       (W, H, cspp, args.bounces, cores, cpu_dt),
             "cpu_model": cpu_model,
             "reference_split_16_column_stripes": {"value": W * H / ref_dt, "threads": 16, "spp": 1, "seconds": ref_dt},

@@ -479,6 +479,7 @@ typedef struct worker {
     srt_oracle_job* job;
     int32_t minX, maxX, minY, maxY; /* scene coordinates, max exclusive */
     int x_outer;                    /* reference walk order :235-237 */
+    int y_step;                     /* row interleave: thread t takes rows minY, minY + y_step, ... */
     int literal_blocks;             /* run renderArea's own block loop nest (SPLIT_REF_COLS + steps) */
     uint64_t rays;
 } worker;
@@ -562,7 +563,8 @@ static void* worker_main(void* arg) {
         for (int x = w->minX; x < w->maxX; x++)
             for (int y = w->minY; y < w->maxY; y++) render_pixel(&c, job, x, y);
     } else {
-        for (int y = w->minY; y < w->maxY; y++)
+        const int step = w->y_step > 0 ? w->y_step : 1;
+        for (int y = w->minY; y < w->maxY; y += step)
             for (int x = w->minX; x < w->maxX; x++) render_pixel(&c, job, x, y);
     }
     w->rays = c.rays;
@@ -607,15 +609,16 @@ int srt_oracle_render(srt_oracle_job* job) {
             n++;
         }
     } else {
+        /* rows are dealt round-robin to the threads: sky rows are ~10x cheaper than floor rows, so
+         * contiguous bands would leave most threads idle (results do not depend on the split) */
         int rows = y1 - y0;
-        for (int i = 0; i < T; i++) {
-            int a = y0 + (int)((long long)rows * i / T), b = y0 + (int)((long long)rows * (i + 1) / T);
-            if (a >= b) continue;
+        for (int i = 0; i < T && i < rows; i++) {
             ws[n].job = job;
             ws[n].minX = 0;
             ws[n].maxX = W;
-            ws[n].minY = a;
-            ws[n].maxY = b;
+            ws[n].minY = y0 + i;
+            ws[n].maxY = y1;
+            ws[n].y_step = T;
             ws[n].x_outer = 0;
             n++;
         }

@@ -25,7 +25,7 @@ extern "C" {
 #define SRT_ORACLE_POW_SHARED 1 /* srt_powf (include/srt_defs.h) — bit-comparable with the GPU */
 
 /* how the image is split over CPU threads (results are identical; timing differs) */
-#define SRT_ORACLE_SPLIT_ROWS 0    /* contiguous row bands, one per thread */
+#define SRT_ORACLE_SPLIT_ROWS 0    /* rows dealt round-robin to the threads (balanced) */
 #define SRT_ORACLE_SPLIT_REF_COLS 1 /* reference-faithful: `threads` column stripes of
                                        ceil(W/threads)+1, x-outer/y-inner walk
                                        (Raytracer.cpp:235-237,330-342) */
