@@ -1,34 +1,41 @@
-// srt_kernel.hip.h — gfx950 (CDNA4) path-trace kernel: one work-item = one pixel.
+// srt_kernel.hip.h — gfx950 (CDNA4) path-trace kernel.
 //
 // What it computes is, bit for bit, the reference's per-pixel loop
 //   GetRayDirection -> RaytraceScene -> SetScreenPixel   (Raytracer/Raytracer.cpp:63-213)
 // with Object.hpp's Sphere / Box intersectors and Common.hpp's float3 / Color value
-// semantics, for `sample_count` successive frames in one launch.  HOW it computes it is
-// MI355X-first and shares nothing with the reference's structure:
+// semantics, for `sample_count` successive frames in one launch (plus the preview shader,
+// progressive blocks and picking of Raytracer.cpp:147-160, 233-248, 525-541).  HOW it computes
+// it is MI355X-first and shares nothing with the reference's structure:
 //
-//   * wavefront (64 lanes) = 8x8 pixel tile; workgroup = 4 waves = 16x16 pixels.
-//   * the flattened scene (spheres as (c.xyz, r^2) float4, boxes as two float4, a
-//     48-byte material row per primitive) is staged ONCE per workgroup into LDS; in the
-//     closest-hit scan every lane reads the same LDS address (ds_read_b128 broadcast,
-//     conflict-free), so the scan is pure VALU.
-//   * the scan keeps only (best distance, primitive id); the expensive hit record
-//     (sqrt, point, normal) is computed under a __ballot-uniform branch only when some
-//     lane of the wave passes the cheap d2 <= r^2 test, and the normal/point only once
-//     for the winner after the scan.
-//   * primary rays do not depend on the sample (no jitter, Raytracer.cpp:109-110), so
-//     the primary hit is found once per pixel and reused by every sample.
-//   * per-lane path regeneration: a lane whose path ended accumulates its sample and
-//     immediately starts the next one, so the wave loops max_lane(sum of rays) times,
-//     not sum_samples(max_lane(rays)).
-//   * the accumulator (running mean, Raytracer.cpp:65-71) lives in registers for the
-//     whole launch: one 16-byte accumulator store + one 4-byte ARGB store per pixel.
+//   * one work-item = one pixel for set-up and output; wavefront (64 lanes) = 8x8 pixel tile;
+//     workgroup = 4 waves = 16x16 pixels; 128 VGPRs -> 4 waves per SIMD.
+//   * the flattened scene image (srt_scene_image.h) is staged ONCE per workgroup into LDS.
+//   * primary rays do not depend on the sample (no jitter, Raytracer.cpp:109-110): the primary
+//     hit is found once per pixel; pixels whose colour is sample-invariant finish immediately.
+//   * wave-level path pool: traced pixels are compacted into slots (ballot + mbcnt); free lanes
+//     pull (slot, sample) tasks, finished sample colours go through an LDS ring and are folded
+//     into the order-dependent running mean (Raytracer.cpp:65-71) strictly in sample order by the
+//     slot's owner lane; one 16-byte accumulator store + one 4-byte ARGB store per pixel.
+//   * closest_hit runs in wave-uniform control flow (idle lanes help):
+//       - few large "uniform" spheres: broadcast ds_read_b128, exact arithmetic, sqrt only under
+//         a ballot-uniform branch;
+//       - small spheres in clusters of K: per-lane conservative bound test (FMA allowed, proven
+//         conservative), then all (ray, cluster) pairs of the wave are compacted into an LDS work
+//         list, lanes pull items, fetch the ray with __shfl, run the EXACT arithmetic and merge
+//         through a 64-bit LDS atomicMin on (ordered distance, list index, primitive);
+//       - boxes: exact iq slab test, per-ray part hoisted;
+//       - EXTENSION, triangle meshes: wave-cooperative BVH traversal (LDS LIFO of (ray, node)
+//         items), srt_mesh_bvh.h.
 //   * counter-based RNG keyed (seed, absolute pixel, sample, draw#): include/srt_defs.h.
 //
 // Bit-exactness rules (the file is compiled with -ffp-contract=off; hipcc's default
 // correctly-rounded fp32 divide/sqrt stays on; fp32 denormals are not flushed):
-//   every expression keeps the reference's association; Color results go through
-//   clamp0() like Color's constructor (Common.hpp:253-262); comparisons keep their NaN
-//   behaviour (a > b ? a : b, never fmaxf).
+//   every expression of the reference keeps its association; Color results go through clamp0()
+//   like Color's constructor (Common.hpp:253-262); comparisons keep their NaN behaviour
+//   (a > b ? a : b, never fmaxf).  Explicit FMAs appear only (a) in conservative filters, where
+//   any rounding is covered by the inflation proofs, (b) in srt_powf / rand_unit, where host and
+//   device execute the same fused operations or the result is verified exhaustively.
+//   Winner updates are written as branch-free selects (see the note in closest_hit).
 #pragma once
 
 #include <hip/hip_runtime.h>
