@@ -91,7 +91,7 @@ constexpr int RING_DEPTH = 4;  // ring entries per slot when all 64 pixels of th
 constexpr int WAVE_SCRATCH_BYTES = 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4 + 64 * RING_DEPTH * 16;
 constexpr int WG_SCRATCH_BYTES = WAVE_SCRATCH_BYTES * WG_TILES_X * WG_TILES_Y;
 // extra per-wave LDS of the mesh kernel: node LIFO + leaf queue of the cooperative BVH traversal
-constexpr int MESH_QN = 1024, MESH_QL = 512;
+constexpr int MESH_QN = 512, MESH_QL = 256;
 constexpr int MESH_WAVE_BYTES = (MESH_QN + MESH_QL) * 4;
 constexpr int WG_MESH_SCRATCH_BYTES = MESH_WAVE_BYTES * WG_TILES_X * WG_TILES_Y;
 
