@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU sample")
     ap.add_argument("--balance", default="cost", choices=["cost", "equal"], help="row-stripe split for N>1")
+    ap.add_argument("--gather", default="p2p", choices=["p2p", "padded"],
+                    help="how cost-balanced (unequal) bands are joined: one grouped isend/irecv in place, or one padded dist.gather")
     ap.add_argument("--mesh", type=int, default=0, metavar="N",
                     help="EXTENSION workload (BASELINE configs[3]): replace Scene1's big ball by an N x N lat-long "
                          "tessellation (224 -> 99,904 triangles); implies --no-cpu-baseline")
@@ -172,18 +174,29 @@ def main():
         if rehearsal and world > 1:  # gloo cannot move device memory: stage through the host
             stream.synchronize()
             host_frame[rb:re].copy_(frame[rb:re])
-            stripes.gather_bands(host_frame, bands, rank, world, dist)
+            stripes.gather_bands(host_frame, bands, rank, world, dist, method=args.gather)
         else:
-            stripes.gather_bands(frame, bands, rank, world, dist)
+            stripes.gather_bands(frame, bands, rank, world, dist, method=args.gather)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
+    try:
+        for _ in range(max(args.warmup, 1) if world > 1 else args.warmup):
+            step()
+        fence()
+    except RuntimeError as e:  # a backend that rejects the grouped point-to-point form
+        if world > 1 and args.gather == "p2p":
+            args.gather = "padded"
+            if rank == 0:
+                print("bench.py: grouped isend/irecv failed (%s); using the padded gather" % str(e).splitlines()[0], file=sys.stderr)
+            for _ in range(max(args.warmup, 1)):
+                step()
+            fence()
+        else:
+            raise
     kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -268,7 +281,7 @@ def main():
                 "workload": "%s.json %dx%d, %d spp (%d per GPU-share), %d bounces, FOV %d, camera at origin" %
                             (args.scene, W, H, spp, args.spp, args.bounces, FOV),
                 "objects": {"spheres": n_sph, "boxes": n_box, "mesh_triangles": n_tri},
-                "partition": "single frame" if world == 1 else "row stripes in memory-row space, %s split, one RCCL gather" % args.balance,
+                "partition": "single frame" if world == 1 else "row stripes in memory-row space, %s split, one RCCL gather (%s)" % (args.balance, args.gather),
                 "bands": bands,
                 "rays_per_sample": rbar,
             },

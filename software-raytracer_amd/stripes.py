@@ -57,14 +57,33 @@ def partition_rows(height: int, world: int, row_cost: Optional[Sequence[float]] 
     return [(bounds[k], bounds[k + 1]) for k in range(world)]
 
 
-def gather_bands(frame, bands: Sequence[Tuple[int, int]], rank: int, world: int, dist, dst: int = 0):
+def gather_bands(frame, bands: Sequence[Tuple[int, int]], rank: int, world: int, dist, dst: int = 0,
+                 method: str = "p2p"):
     """Join the ranks' bands on rank `dst`.
 
     frame: torch tensor [H, W] (uint32 viewed as int32), same shape on every rank; rank k has
     rendered rows bands[k].  After the call rank `dst`'s frame holds every band.  One
-    collective: dist.gather for equal bands, one batched isend/irecv otherwise.
+    collective: dist.gather for equal bands; for unequal bands either one batched isend/irecv
+    received in place (method "p2p") or one dist.gather of bands padded to the tallest one
+    followed by an unpack on `dst` (method "padded").
     """
     if world == 1:
+        return
+    if method == "padded" and len({b - a for a, b in bands}) > 1:
+        import torch
+
+        rows = max(b - a for a, b in bands)
+        a, b = bands[rank]
+        send = torch.zeros((rows, frame.shape[1]), dtype=frame.dtype, device=frame.device)
+        send[: b - a].copy_(frame[a:b])
+        if rank == dst:
+            stage = [torch.empty_like(send) for _ in range(world)]
+            dist.gather(send, gather_list=stage, dst=dst)
+            for k, (x, y) in enumerate(bands):
+                if k != dst:
+                    frame[x:y].copy_(stage[k][: y - x])
+        else:
+            dist.gather(send, gather_list=None, dst=dst)
         return
     sizes = {b - a for a, b in bands}
     if len(sizes) == 1:
