@@ -167,13 +167,16 @@ def main():
         # each band's row costs are rescaled so that the band's total matches its measured time, then
         # the rows are re-partitioned.  A few rounds converge; every rank computes the same split.
         cal_spp = max(2, spp // 8)
-        for _ in range(4):
+        best_bands, best_max = bands, float("inf")
+        for _ in range(5):
             a, b = bands[rank]
             pt.render(spp=cal_spp, bounces=args.bounces, seed=SEED, first_sample=1, reset=True, rows=(a, b))
             t_loc = torch.tensor([pt.stats().kernel_ms], dtype=torch.float64, device=cdev)
             t_all = [torch.zeros_like(t_loc) for _ in range(world)]
             dist.all_gather(t_all, t_loc)
             times = [float(t.item()) for t in t_all]
+            if max(times) < best_max:  # keep the best MEASURED split (identical decision on every rank)
+                best_bands, best_max = bands, max(times)
             if max(times) <= 1.03 * (sum(times) / world):
                 break
             for k, (x, y) in enumerate(bands):
@@ -182,6 +185,7 @@ def main():
                 for r in range(x, y):
                     row_cost[r] *= f
             bands = stripes.partition_rows(H, world, row_cost, align=1)
+        bands = best_bands
     else:
         bands = stripes.partition_rows(H, world)
     rb, re = bands[rank]
