@@ -245,7 +245,12 @@ int srt_set_scene(srt_context* ctx, const srt_object* objects, size_t count) {
     ctx->d_bvh_nodes = ctx->d_bvh_tris = nullptr;
     ctx->d_bvh_gidpos = nullptr;
     if (ctx->mesh_image.n_tris > 0) {
-        if (ctx->mesh_image.max_depth > 26) return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: BVH too deep (%d)", ctx->mesh_image.max_depth);
+        // strict depth-first traversal (the kernel's last resort) keeps at most 7 entries per level
+        if (7 * ctx->mesh_image.max_depth + 8 > srt::MESH_QN)
+            return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: BVH too deep (%d levels)", ctx->mesh_image.max_depth);
+        for (int ax = 0; ax < 3; ++ax)  // keeps cell * slope finite in the kernel's plane distances
+            if (!(fabsf(ctx->mesh_image.center[ax]) + ctx->mesh_image.half[ax] <= 1e9f))
+                return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: mesh coordinates beyond 1e9 are not supported");
         SRT_HIP(ctx, hipMalloc((void**)&ctx->d_bvh_nodes, ctx->mesh_image.nodes.size() * sizeof(float4)));
         SRT_HIP(ctx, hipMalloc((void**)&ctx->d_bvh_tris, ctx->mesh_image.tris.size() * sizeof(float4)));
         SRT_HIP(ctx, hipMemcpyAsync(ctx->d_bvh_nodes, ctx->mesh_image.nodes.data(), ctx->mesh_image.nodes.size() * sizeof(float4),
@@ -361,6 +366,7 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
     }();
     use = ctx->variant >= 0 ? ctx->variant : variant;
     const int img = (use == 2) ? 1 : 0;  // variant 2: plain brute-force image
+    K.mesh_defer = use >= 100 ? use - 100 : 16;  // variants 100 + n: mesh phases wait for n rays
     const srt::SceneLayout& SL = ctx->layout[img];
     K.nu4 = SL.nu4;
     K.nc = SL.nc;
@@ -377,7 +383,8 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
     K.bvh_gidpos = ctx->d_bvh_gidpos;
     K.n_tris = ctx->mesh_image.n_tris;
     for (int i = 0; i < 3; ++i) K.mesh_center[i] = ctx->mesh_image.center[i], K.mesh_half[i] = ctx->mesh_image.half[i];
-    K.mesh_r1 = ctx->mesh_image.half[0] + ctx->mesh_image.half[1] + ctx->mesh_image.half[2];
+    K.mesh_r1 = (ctx->mesh_image.half[0] + ctx->mesh_image.half[1] + ctx->mesh_image.half[2]) +
+                (fabsf(ctx->mesh_image.center[0]) + fabsf(ctx->mesh_image.center[1]) + fabsf(ctx->mesh_image.center[2]));
     K.accumulator = ctx->d_acc;
     K.framebuffer = ctx->d_fb;
     K.ray_counter = ctx->d_rays;
@@ -417,11 +424,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     dim3 block(srt::WG_THREADS);
     SRT_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     // variants are a development aid for in-process A/B timing; all are bit-identical
-    if (K.n_tris > 0 && use == 5)
-        hipLaunchKernelGGL((srt::pathtrace_kernel<4, true>), grid, block, lds_bytes, ctx->stream, K);
-    else if (K.n_tris > 0 && use == 6)
-        hipLaunchKernelGGL((srt::pathtrace_kernel<2, true>), grid, block, lds_bytes, ctx->stream, K);
-    else if (K.n_tris > 0)  // EXTENSION: scenes with triangle meshes use the BVH-enabled instantiation
+    if (K.n_tris > 0)  // EXTENSION: scenes with triangle meshes use the BVH-enabled instantiation
         hipLaunchKernelGGL((srt::pathtrace_kernel<3, true>), grid, block, lds_bytes, ctx->stream, K);
     else if (use == 1)
         hipLaunchKernelGGL((srt::pathtrace_kernel<5, false>), grid, block, lds_bytes, ctx->stream, K);

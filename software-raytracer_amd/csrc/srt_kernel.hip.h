@@ -73,7 +73,8 @@ struct KernelParams {
     int32_t n_tris;
     float mesh_center[3];
     float mesh_half[3];  // root box half extents
-    float mesh_r1;       // their sum
+    float mesh_r1;       // their sum + |centre|_1
+    int32_t mesh_defer;  // path pool: fewest rays that start a mesh phase (closest_hit)
     float4* accumulator;
     uint32_t* framebuffer;
     unsigned long long* ray_counter;
@@ -91,7 +92,13 @@ constexpr int RING_DEPTH = 4;  // ring entries per slot when all 64 pixels of th
 constexpr int WAVE_SCRATCH_BYTES = 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4 + 64 * RING_DEPTH * 16;
 constexpr int WG_SCRATCH_BYTES = WAVE_SCRATCH_BYTES * WG_TILES_X * WG_TILES_Y;
 // extra per-wave LDS of the mesh kernel: node LIFO + leaf queue of the cooperative BVH traversal
-constexpr int MESH_QN = 512, MESH_QL = 256;
+constexpr int MESH_QN = 512, MESH_QL = 320;
+#ifdef SRT_STATS  // development build only (make STATS=1|2): traversal counters read by srt_debug_read_stats
+__device__ unsigned long long g_stats[8];
+#define SRT_STAT(i, v) do { if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define SRT_STAT(i, v) do { } while (0)
+#endif
 constexpr int MESH_WAVE_BYTES = (MESH_QN + MESH_QL) * 4;
 constexpr int WG_MESH_SCRATCH_BYTES = MESH_WAVE_BYTES * WG_TILES_X * WG_TILES_Y;
 
@@ -212,7 +219,7 @@ __device__ __forceinline__ void hit_unkey(unsigned long long k, float& t, int& p
 //      LDS atomicMin on hit_key — so the wave does sum(pairs)/64 rounds, not max-per-lane.
 //   3. boxes: every lane, exact arithmetic.
 template <bool MESH>
-__device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, V3 o, V3 d, bool active) {
+__device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, V3 o, V3 d, bool active, int defer_min, bool& deferred) {
     float best = __builtin_inff();
     int bp = -1;
     // exact sphere test of ray (ro, rd) against four spheres; updates (tb, pb) with the tie rule.
@@ -362,21 +369,19 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             }
         }
     }
-    // ---- 4. EXTENSION: triangle meshes — per-lane traversal of the host-built BVH (HBM/L2).
+    // ---- 4. EXTENSION: triangle meshes — traversal of the host-built 8-wide BVH (HBM/L2).
     // The triangle arithmetic is this project's definition (srt_pathtrace.h); the box filter is
-    // conservative: boxes are padded per ray by 1e-5 * (distance of the origin to the mesh +
-    // mesh size), far above the rounding of the Moller-Trumbore test (~1e-6 * |o - v0|), and the
-    // slab comparison itself has slack for the approximate reciprocals.
+    // conservative: boxes are padded per ray by 1e-5 * (|o - centre|_1 + |centre|_1 + mesh size), a
+    // bound on every coordinate and distance involved, far above the rounding of the
+    // Moller-Trumbore test (~1e-6 * |o - v0|) and of the plane distances below (~4e-7 of the same
+    // magnitudes); the slab comparison itself has slack for the approximate reciprocals.
     int btri = -1;               // winner's position in the triangle array (-1: not a triangle)
-    int bgid = 0x7fffffff;       // its global triangle id
-    int bord = 0x7fffffff;       // list index of the current best hit's object (registers only in the traversal)
+    int bord = 0x7fffffff;       // list index of the best analytic hit's object
     if constexpr (MESH) {
         if (P.n_tris > 0) {
             if (bp >= 0) bord = S.order(bp);
             const float pad = 1e-5f * (((fabsf(o.x - P.mesh_center[0]) + fabsf(o.y - P.mesh_center[1])) + fabsf(o.z - P.mesh_center[2])) + P.mesh_r1) + 1e-7f;
             const V3 inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-            int stack[28];
-            int sp = 0, node = 0;
             // root box (kernel argument, no memory access): most rays never come near the mesh, and
             // when no lane of the wave does, the whole phase is skipped
             bool go;
@@ -388,67 +393,41 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                 float tmax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
                 go = active && tmin <= tmax * 1.00001f + 1e-6f && tmax >= 0.0f && tmin <= 10001.0f && tmin * 0.9999f - 1e-5f <= best;
             }
-            // exact test of the (up to 4) triangles of a leaf; ref = -(1 + first*4 + (count-1))
-            auto leaf = [&](int ref) {
-                const int v = -ref - 1, first = v >> 2, cnt = (v & 3) + 1;
-                for (int k = 0; k < 4; ++k) {
-                    if (k < cnt) {
-                        const float4 a = P.bvh_tris[3 * (first + k)], b = P.bvh_tris[3 * (first + k) + 1], c = P.bvh_tris[3 * (first + k) + 2];
-                        // Moller-Trumbore, binary32, no FMA, fixed order (the oracle's triangle_raytrace)
-                        V3 pv = v3(d.y * c.z - d.z * c.y, d.z * c.x - d.x * c.z, d.x * c.y - d.y * c.x);
-                        float det = (b.x * pv.x + b.y * pv.y) + b.z * pv.z;
-                        float idet = 1.0f / det;
-                        V3 tv = v3(o.x - a.x, o.y - a.y, o.z - a.z);
-                        float u = ((tv.x * pv.x + tv.y * pv.y) + tv.z * pv.z) * idet;
-                        V3 qv = v3(tv.y * b.z - tv.z * b.y, tv.z * b.x - tv.x * b.z, tv.x * b.y - tv.y * b.x);
-                        float vv = ((d.x * qv.x + d.y * qv.y) + d.z * qv.z) * idet;
-                        float t = ((c.x * qv.x + c.y * qv.y) + c.z * qv.z) * idet;
-                        const bool ok = (fabsf(det) >= 1e-12f) & (u >= 0.0f) & (u <= 1.0f) & (vv >= 0.0f) & (u + vv <= 1.0f) &
-                                        (t >= (float)0.01) & (t <= 10000.0f);
-                        const int ord = __float_as_int(c.w), gid = __float_as_int(b.w);
-                        // (distance, list index, triangle id) lexicographic minimum.  Written as
-                        // branch-free boolean algebra + selects on purpose: hipcc (ROCm 7.2) lowers the
-                        // nested short-circuit form of this update into exec-mask code that loses one of
-                        // the state updates for lanes winning through the tie term (seen in the ISA).
-                        const bool win = ok & ((t < best) | ((t == best) & ((ord < bord) | ((ord == bord) & (gid < bgid)))));
-                        best = win ? t : best;
-                        bp = win ? __float_as_int(a.w) : bp;
-                        btri = win ? first + k : btri;
-                        bgid = win ? gid : bgid;
-                        bord = win ? ord : bord;
-                    }
-                }
-            };
-            // entry distance of the ray into a padded box, +inf when it misses (NaN-suppressing
-            // min/max: v_min/v_max return the non-NaN operand)
-            auto entry = [&](float lx, float ly, float lz, float hx, float hy, float hz) {
-                float t1x = ((lx - pad) - o.x) * inv.x, t2x = ((hx + pad) - o.x) * inv.x;
-                float t1y = ((ly - pad) - o.y) * inv.y, t2y = ((hy + pad) - o.y) * inv.y;
-                float t1z = ((lz - pad) - o.z) * inv.z, t2z = ((hz + pad) - o.z) * inv.z;
-                float tmin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
-                float tmax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
-                const bool hit = tmin <= tmax * 1.00001f + 1e-6f && tmax >= 0.0f && tmin <= 10001.0f;
-                return hit ? tmin : __builtin_inff();
-            };
-            // ---- wave-cooperative traversal.  Rays that come near the mesh put (ray lane, node) items on
-            // a LIFO in LDS; every round all 64 lanes pop items, fetch the item's ray with __shfl, test
-            // the node's two child boxes and push the survivors with ballot prefix sums (far child first,
-            // so the near one is popped first).  Leaves go to a second queue and are tested 64 at a
-            // time.  A ray's best triangle is merged through a 64-bit LDS atomicMin on
-            // (ordered t || global triangle id) — the id order is (list order of the object, triangle
-            // index), i.e. the tie rule — and doubles as the culling distance.  If a queue would
-            // overflow, the exact per-lane traversal below redoes the phase from scratch.
-            bool overflow = false;
-            if (__builtin_amdgcn_ballot_w64(go) != 0ull) {
+            // ---- wave-cooperative traversal of the 8-wide BVH.  Rays that come near the mesh put
+            // (ray lane, node) items on a LIFO in LDS.  A node round pops items and tests the 8 quantized
+            // child boxes of each: with <= 8 items waiting, eight lanes share an item (one child per lane, so
+            // a lone ray still uses the wave and descends a level per round); with more, one lane per item
+            // loops over the children.  Surviving children are pushed with ballot prefix sums, leaves to a
+            // second queue that is drained a triangle per lane (<= 16 leaves waiting) or a leaf per lane.
+            // A ray's best triangle is merged through a 64-bit LDS atomicMin on (ordered t || global
+            // triangle id) — the id order is (list order of the object, triangle index), i.e. the tie
+            // rule — and doubles as the culling distance.  The merge is idempotent, so when a queue would
+            // overflow the batch is simply abandoned and redone with fewer rays at a time; one ray
+            // popping one item per round (strict depth-first) is bounded by 7 * depth + 8 entries, which
+            // the host checks against MESH_QN.
+            //
+            // Deferral (path pool only): a mesh phase costs a chain of dependent memory round trips however
+            // few rays take part, and most phases would be started by two or three stray bounce rays.  So
+            // unless at least `defer_min` rays want the mesh — or no lane has anything else to do — the
+            // rays are reported back as deferred: the pool parks them and offers them again next round.
+            unsigned long long pend = __builtin_amdgcn_ballot_w64(go);
+            const int n_go = __builtin_popcountll(pend);
+            if (n_go < defer_min && n_go != __builtin_popcountll(__builtin_amdgcn_ballot_w64(active))) {
+                deferred = go;
+                pend = 0ull;
+            } else {
+                deferred = false;
+            }
+            if (pend != 0ull) {
                 const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
                 unsigned* qn = S.meshq;
                 unsigned* ql = S.meshq + MESH_QN;
-                int nN = 0, nL = 0;
                 auto okey = [](float t) {  // order-preserving float -> uint
                     unsigned u = __float_as_uint(t + 0.0f);
                     return u ^ ((u & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);
                 };
                 auto unkey = [](unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u); };
+                bool overflow = false;
                 auto push = [&](bool pred, unsigned item, unsigned* q, int& n, int cap) {
                     const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
                     const int cnt = __builtin_popcountll(m);
@@ -460,75 +439,153 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                     }
                 };
                 S.res[lane] = ((unsigned long long)okey(best) << 32) | 0xFFFFFFFFull;  // no triangle yet
-                push(go, (unsigned)lane << 26, qn, nN, MESH_QN);
-                __builtin_amdgcn_wave_barrier();
-                while (!overflow && (nN > 0 || nL > 0)) {
-                    const bool node_round = nN > 0 && nL <= MESH_QL - 128;
-                    int& n = node_round ? nN : nL;
-                    const int take = n < 64 ? n : 64;
-                    n -= take;
-                    const bool on = lane < take;
-                    const unsigned item = on ? (node_round ? qn : ql)[n + lane] : ((unsigned)lane << 26);
-                    const int src = (int)(item >> 26), code = (int)(item & 0x3FFFFFFu);
-                    const V3 ro = v3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
-                    const V3 rd = v3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
-                    const float rpad = __shfl(pad, src);
-                    __builtin_amdgcn_wave_barrier();
-                    if (node_round) {
-                        const V3 rinv = v3(__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y), __builtin_amdgcn_rcpf(rd.z));
-                        const float thr = unkey((unsigned)(S.res[src] >> 32));
-                        const float4 n0 = P.bvh_nodes[4 * code], n1 = P.bvh_nodes[4 * code + 1], n2 = P.bvh_nodes[4 * code + 2],
-                                     n3 = P.bvh_nodes[4 * code + 3];
-                        auto entry2 = [&](float lx, float ly, float lz, float hx, float hy, float hz) {
-                            float t1x = ((lx - rpad) - ro.x) * rinv.x, t2x = ((hx + rpad) - ro.x) * rinv.x;
-                            float t1y = ((ly - rpad) - ro.y) * rinv.y, t2y = ((hy + rpad) - ro.y) * rinv.y;
-                            float t1z = ((lz - rpad) - ro.z) * rinv.z, t2z = ((hz + rpad) - ro.z) * rinv.z;
-                            float tmin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
-                            float tmax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
-                            const bool hit = tmin <= tmax * 1.00001f + 1e-6f && tmax >= 0.0f && tmin <= 10001.0f;
-                            return hit ? tmin : __builtin_inff();
-                        };
-                        float tl = entry2(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y);
-                        float tr = entry2(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w);
-                        int rl = __float_as_int(n3.x), rr = __float_as_int(n3.y);
-                        const bool swap = tr < tl;
-                        const float tnear = swap ? tr : tl, tfar = swap ? tl : tr;
-                        const int rnear = swap ? rr : rl, rfar = swap ? rl : rr;
-                        const bool vn = on & (tnear < __builtin_inff()) & (tnear * 0.9999f - 1e-5f <= thr);
-                        const bool vf = on & (tfar < __builtin_inff()) & (tfar * 0.9999f - 1e-5f <= thr);
-                        const unsigned tag = (unsigned)src << 26;
-                        push(vf & (rfar >= 0), tag | (unsigned)rfar, qn, nN, MESH_QN);
-                        push(vn & (rnear >= 0), tag | (unsigned)rnear, qn, nN, MESH_QN);
-                        push(vf & (rfar < 0), tag | (unsigned)(-rfar - 1), ql, nL, MESH_QL);
-                        push(vn & (rnear < 0), tag | (unsigned)(-rnear - 1), ql, nL, MESH_QL);
-                    } else {
-                        const int first = code >> 2, cnt = (code & 3) + 1;
-                        float tb = __builtin_inff();
-                        int gb = 0x7fffffff;
-                        for (int k = 0; k < 4; ++k) {
-                            const int q = first + (k < cnt ? k : 0);
-                            const float4 a = P.bvh_tris[3 * q], b = P.bvh_tris[3 * q + 1], c = P.bvh_tris[3 * q + 2];
-                            // Moller-Trumbore, binary32, no FMA, fixed order (the oracle's triangle_raytrace)
-                            V3 pv = v3(rd.y * c.z - rd.z * c.y, rd.z * c.x - rd.x * c.z, rd.x * c.y - rd.y * c.x);
-                            float det = (b.x * pv.x + b.y * pv.y) + b.z * pv.z;
-                            float idet = 1.0f / det;
-                            V3 tv = v3(ro.x - a.x, ro.y - a.y, ro.z - a.z);
-                            float u = ((tv.x * pv.x + tv.y * pv.y) + tv.z * pv.z) * idet;
-                            V3 qv = v3(tv.y * b.z - tv.z * b.y, tv.z * b.x - tv.x * b.z, tv.x * b.y - tv.y * b.x);
-                            float vv = ((rd.x * qv.x + rd.y * qv.y) + rd.z * qv.z) * idet;
-                            float t = ((c.x * qv.x + c.y * qv.y) + c.z * qv.z) * idet;
-                            const bool ok = on & (k < cnt) & (fabsf(det) >= 1e-12f) & (u >= 0.0f) & (u <= 1.0f) & (vv >= 0.0f) & (u + vv <= 1.0f) &
-                                            (t >= (float)0.01) & (t <= 10000.0f);
-                            const int gid = __float_as_int(b.w);
-                            const bool win = ok & ((t < tb) | ((t == tb) & (gid < gb)));
-                            tb = win ? t : tb;
-                            gb = win ? gid : gb;
-                        }
-                        if (gb != 0x7fffffff) atomicMin(&S.res[src], ((unsigned long long)okey(tb) << 32) | (unsigned)gb);
-                    }
-                    __builtin_amdgcn_wave_barrier();
+                int batch = 64;
+                bool strict = false;
+#ifdef SRT_STATS
+                const int st_cls = n_go <= 2 ? 0 : n_go <= 8 ? 1 : n_go <= 32 ? 2 : 3;
+                int st_rounds = 0;
+                if (SRT_STATS == 1) {
+                    SRT_STAT(1, n_go);
+                    SRT_STAT(0, 1);
                 }
-                if (!overflow) {  // the ray's best triangle, if any, against the best analytic hit
+#endif
+                while (pend != 0ull) {
+                    // the next (up to `batch`) waiting rays enter at the root
+                    const bool mine = (pend >> lane) & 1ull;
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pend >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pend, 0u));
+                    const bool sel = mine && rank < batch;
+                    const unsigned long long selmask = __builtin_amdgcn_ballot_w64(sel);
+                    int nN = 0, nL = 0;
+                    overflow = false;
+                    push(sel, (unsigned)lane << 26, qn, nN, MESH_QN);
+                    __builtin_amdgcn_wave_barrier();
+                    while (!overflow && (nN > 0 || nL > 0)) {
+                        const bool node_round = nN > 0 && nL < 64;
+                        // eight lanes per node / four per leaf when few items wait
+                        const bool wide = strict || (node_round ? nN <= 8 : nL <= 16);
+                        const int per = wide ? (node_round ? 8 : 4) : 1;
+                        int& n = node_round ? nN : nL;
+                        int take = n < 64 / per ? n : 64 / per;
+                        if (strict && node_round) take = 1;
+                        if (node_round && !wide) {  // leave room for the expected pushes (about 3 per item)
+                            int room = (MESH_QN - nN) / 3;
+                            const int lroom = (MESH_QL - nL) / 3;
+                            room = room < lroom ? room : lroom;
+                            room = room < 8 ? 8 : room;
+                            take = take < room ? take : room;
+                        }
+                        n -= take;
+#ifdef SRT_STATS
+                        if (SRT_STATS == 1) {
+                            SRT_STAT(node_round ? 2 : 4, 1);
+                            SRT_STAT(node_round ? 3 : 5, take);
+                        }
+                        st_rounds += 1;
+#endif
+                        const int slot = wide ? (node_round ? lane >> 3 : lane >> 2) : lane;
+                        const bool on = slot < take;
+                        const unsigned item = on ? (node_round ? qn : ql)[n + slot] : 0u;  // item 0 = (lane 0, root / first leaf): valid memory
+                        const int src = (int)(item >> 26), code = (int)(item & 0x3FFFFFFu);
+                        const V3 ro = v3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
+                        const V3 rd = v3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
+                        const float rpad = __shfl(pad, src);
+                        __builtin_amdgcn_wave_barrier();
+                        if (node_round) {
+                            const float thr = unkey((unsigned)(S.res[src] >> 32));
+                            const float4 n0 = P.bvh_nodes[6 * code], n1 = P.bvh_nodes[6 * code + 1], n2 = P.bvh_nodes[6 * code + 2],
+                                         n3 = P.bvh_nodes[6 * code + 3], n4 = P.bvh_nodes[6 * code + 4], n5 = P.bvh_nodes[6 * code + 5];
+                            // slopes clamped to 2^96: an axis the ray (almost) does not move along keeps its
+                            // sign-correct, still astronomically large plane distances without inf * 0
+                            const float BIG = 0x1p96f;
+                            const V3 rinv = v3(fminf(fmaxf(__builtin_amdgcn_rcpf(rd.x), -BIG), BIG), fminf(fmaxf(__builtin_amdgcn_rcpf(rd.y), -BIG), BIG),
+                                               fminf(fmaxf(__builtin_amdgcn_rcpf(rd.z), -BIG), BIG));
+                            const unsigned ex = __float_as_uint(n0.w);
+                            // plane distance = q * (cell * rinv) + ((origin -/+ pad) - ro) * rinv, one FMA per plane
+                            const float sx = __uint_as_float((ex & 255u) << 23) * rinv.x, sy = __uint_as_float(((ex >> 8) & 255u) << 23) * rinv.y,
+                                        sz = __uint_as_float(((ex >> 16) & 255u) << 23) * rinv.z;
+                            const float lx0 = ((n0.x - rpad) - ro.x) * rinv.x, hx0 = ((n0.x + rpad) - ro.x) * rinv.x;
+                            const float ly0 = ((n0.y - rpad) - ro.y) * rinv.y, hy0 = ((n0.y + rpad) - ro.y) * rinv.y;
+                            const float lz0 = ((n0.z - rpad) - ro.z) * rinv.z, hz0 = ((n0.z + rpad) - ro.z) * rinv.z;
+                            const unsigned tag = (unsigned)src << 26;
+                            auto byte_of = [](float lo4, float hi4, int c) {
+                                const unsigned w = __float_as_uint(c >= 4 ? hi4 : lo4);
+                                return (float)((w >> ((c & 3) * 8)) & 255u);
+                            };
+                            auto child = [&](int c) {
+                                const float t1x = __builtin_fmaf(byte_of(n1.x, n1.y, c), sx, lx0), t2x = __builtin_fmaf(byte_of(n2.z, n2.w, c), sx, hx0);
+                                const float t1y = __builtin_fmaf(byte_of(n1.z, n1.w, c), sy, ly0), t2y = __builtin_fmaf(byte_of(n3.x, n3.y, c), sy, hy0);
+                                const float t1z = __builtin_fmaf(byte_of(n2.x, n2.y, c), sz, lz0), t2z = __builtin_fmaf(byte_of(n3.z, n3.w, c), sz, hz0);
+                                const float tmin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+                                const float tmax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+                                const float4 rlo = c >= 4 ? n5 : n4;
+                                const int cc = c & 3;
+                                const int ref = __float_as_int(cc == 0 ? rlo.x : cc == 1 ? rlo.y : cc == 2 ? rlo.z : rlo.w);
+                                // entered only if a triangle inside could still beat the ray's best hit
+                                const bool hit = on & (ref != 0) & (tmin <= tmax * 1.00001f + 1e-6f) & (tmax >= 0.0f) & (tmin <= 10001.0f) &
+                                                 (tmin * 0.9999f - 1e-5f <= thr);
+                                push(hit & (ref > 0), tag | (unsigned)ref, qn, nN, MESH_QN);
+                                push(hit & (ref < 0), tag | (unsigned)(-ref - 1), ql, nL, MESH_QL);
+                            };
+                            if (wide) {
+                                child(lane & 7);
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < 8; ++c) child(c);
+                            }
+                        } else {
+                            const int first = code >> 2, cnt = (code & 3) + 1;
+                            float tb = __builtin_inff();
+                            int gb = 0x7fffffff;
+                            auto triangle = [&](int k) {
+                                const int q = first + (k < cnt ? k : 0);
+                                const float4 a = P.bvh_tris[3 * q], b = P.bvh_tris[3 * q + 1], c = P.bvh_tris[3 * q + 2];
+                                // Moller-Trumbore, binary32, no FMA, fixed order (the oracle's triangle_raytrace)
+                                V3 pv = v3(rd.y * c.z - rd.z * c.y, rd.z * c.x - rd.x * c.z, rd.x * c.y - rd.y * c.x);
+                                float det = (b.x * pv.x + b.y * pv.y) + b.z * pv.z;
+                                float idet = 1.0f / det;
+                                V3 tv = v3(ro.x - a.x, ro.y - a.y, ro.z - a.z);
+                                float u = ((tv.x * pv.x + tv.y * pv.y) + tv.z * pv.z) * idet;
+                                V3 qv = v3(tv.y * b.z - tv.z * b.y, tv.z * b.x - tv.x * b.z, tv.x * b.y - tv.y * b.x);
+                                float vv = ((rd.x * qv.x + rd.y * qv.y) + rd.z * qv.z) * idet;
+                                float t = ((c.x * qv.x + c.y * qv.y) + c.z * qv.z) * idet;
+                                const bool ok = on & (k < cnt) & (fabsf(det) >= 1e-12f) & (u >= 0.0f) & (u <= 1.0f) & (vv >= 0.0f) & (u + vv <= 1.0f) &
+                                                (t >= (float)0.01) & (t <= 10000.0f);
+                                const int gid = __float_as_int(b.w);
+                                // (distance, triangle id) lexicographic minimum.  Written as branch-free boolean
+                                // algebra + selects on purpose: hipcc (ROCm 7.2) lowers the nested short-circuit
+                                // form of such an update into exec-mask code that loses one of the state updates
+                                // for lanes winning through the tie term (seen in the ISA).
+                                const bool win = ok & ((t < tb) | ((t == tb) & (gid < gb)));
+                                tb = win ? t : tb;
+                                gb = win ? gid : gb;
+                            };
+                            if (wide) {
+                                triangle(lane & 3);
+                            } else {
+                                for (int k = 0; k < 4; ++k) triangle(k);
+                            }
+                            if (gb != 0x7fffffff) atomicMin(&S.res[src], ((unsigned long long)okey(tb) << 32) | (unsigned)gb);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    if (!overflow) {
+                        pend &= ~selmask;
+                    } else if (batch > 1) {
+                        batch = batch > 4 ? batch >> 2 : 1;
+                    } else {
+                        strict = true;  // cannot overflow: the host bounds 7 * depth + 8 by MESH_QN
+                    }
+#ifdef SRT_STATS
+                    if (SRT_STATS == 1 && overflow) SRT_STAT(6, 1);
+#endif
+                }
+#ifdef SRT_STATS
+                if (SRT_STATS == 2) {  // histogram by the number of rays entering the phase: phases / rounds per class
+                    SRT_STAT(st_cls, 1);
+                    SRT_STAT(4 + st_cls, st_rounds);
+                }
+#endif
+                {  // the ray's best triangle, if any, against the best analytic hit
                     const unsigned long long r = S.res[lane];
                     const unsigned gid = (unsigned)r;
                     if (go && gid != 0xFFFFFFFFu) {
@@ -539,51 +596,9 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                         best = win ? tm : best;
                         bp = win ? __float_as_int(P.bvh_tris[3 * pos].w) : bp;
                         btri = win ? pos : btri;
-                        bgid = win ? (int)gid : bgid;
-                        bord = win ? ordm : bord;
                     }
-                    go = false;
                 }
                 __builtin_amdgcn_wave_barrier();
-            }
-            // ---- exact per-lane traversal: the fallback when a queue overflowed
-            while (__builtin_amdgcn_ballot_w64(go) != 0ull) {
-                if (go) {
-                    const float4 n0 = P.bvh_nodes[4 * node], n1 = P.bvh_nodes[4 * node + 1], n2 = P.bvh_nodes[4 * node + 2],
-                                 n3 = P.bvh_nodes[4 * node + 3];
-                    float tl = entry(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y);
-                    float tr = entry(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w);
-                    int rl = __float_as_int(n3.x), rr = __float_as_int(n3.y);
-                    if (tr < tl) {  // near child first
-                        float tt = tl;
-                        tl = tr;
-                        tr = tt;
-                        int rt = rl;
-                        rl = rr;
-                        rr = rt;
-                    }
-                    // a child is entered only if a triangle inside could still beat `best`
-                    bool vl = tl < __builtin_inff() && tl * 0.9999f - 1e-5f <= best;
-                    if (vl && rl < 0) {  // near leaf: test now, so the far child sees the new best
-                        leaf(rl);
-                        vl = false;
-                    }
-                    bool vr = tr < __builtin_inff() && tr * 0.9999f - 1e-5f <= best;
-                    if (vr && rr < 0) {
-                        leaf(rr);
-                        vr = false;
-                    }
-                    if (vl) {  // inner children: descend into the near one, stack the far one
-                        if (vr) stack[sp++] = rr;
-                        node = rl;
-                    } else if (vr) {
-                        node = rr;
-                    } else if (sp > 0) {
-                        node = stack[--sp];
-                    } else {
-                        go = false;
-                    }
-                }
             }
         }
     }
@@ -690,7 +705,8 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     const V3 cam = v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
 
     // ---- primary hit: identical for every sample ------------------------------------
-    const Hit h0 = closest_hit<MESH>(S, P, cam, dir0, true);
+    bool parked = false;  // path pool: this lane's ray waits for a mesh phase (see closest_hit)
+    const Hit h0 = closest_hit<MESH>(S, P, cam, dir0, true, 1, parked);
 
     const bool reset = (P.flags & 1u) != 0;
     const uint32_t count = P.sample_count;
@@ -887,7 +903,10 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
 
             // ---- one bounce for every busy lane
             V3 o = v3(0, 0, 0);
-            if (busy) {
+            const float ofs = .00001f;
+            if (MESH && busy && parked) {  // the ray made earlier, offered to the mesh phase again
+                o = v3(hp.x + hn.x * ofs, hp.y + hn.y * ofs, hp.z + hn.z * ofs);
+            } else if (busy) {
                 if (bounce != 0) {  // :169-171
                     T = RGB{clamp0(T.r * 0.8f), clamp0(T.g * 0.8f), clamp0(T.b * 0.8f)};
                 }
@@ -907,12 +926,11 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 float tt = S.mat(hprim, 0).x * spec;
                 V3 l = v3(sr.x * (1 - tt) + refl.x * tt, sr.y * (1 - tt) + refl.y * tt, sr.z * (1 - tt) + refl.z * tt);
                 sray = normalized(l);  // :176
-                const float ofs = .00001f;
                 o = v3(hp.x + hn.x * ofs, hp.y + hn.y * ofs, hp.z + hn.z * ofs);  // :177
             }
             // the scan runs in wave-uniform control flow: idle lanes help with other lanes' rays
-            const Hit h = closest_hit<MESH>(S, P, o, sray, busy);
-            if (busy) {
+            const Hit h = closest_hit<MESH>(S, P, o, sray, busy, P.mesh_defer, parked);
+            if (busy && !(MESH && parked)) {
                 ++rays;
                 bool end_path;
                 if (h.prim < 0) {  // :178-181
@@ -968,7 +986,8 @@ __global__ void __launch_bounds__(64) pick_kernel(const KernelParams P, int px, 
     V3 u = v3(P.right_rd[0] * nX, P.right_rd[1] * nX, P.right_rd[2] * nX);
     V3 vv = v3(P.up_ld[0] * nY, P.up_ld[1] * nY, P.up_ld[2] * nY);
     const V3 dir = normalized(v3((u.x + vv.x) + P.fwd_clip[0], (u.y + vv.y) + P.fwd_clip[1], (u.z + vv.z) + P.fwd_clip[2]));
-    const Hit h = closest_hit<true>(S, P, v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]), dir, true);
+    bool deferred = false;
+    const Hit h = closest_hit<true>(S, P, v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]), dir, true, 1, deferred);
     if (threadIdx.x == 0) {
         out_index[0] = h.prim >= 0 ? S.order(h.prim) : -1;
         out_index[1] = __float_as_int(h.t);

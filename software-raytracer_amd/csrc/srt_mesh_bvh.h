@@ -1,19 +1,22 @@
 // srt_mesh_bvh.h — host-side flattening of SRT_OBJ_MESH objects into one world-space
-// triangle list + a binary BVH (EXTENSION: the reference has no triangle primitive).
+// triangle list + an 8-wide BVH (EXTENSION: the reference has no triangle primitive).
 //
 // Device layout (HBM, read through L2; too large for LDS at 100k triangles):
 //   tris : 3 float4 per triangle, in BVH leaf order
 //            (v0.xyz, bits(primitive id p))      p indexes the LDS material table
 //            (e1.xyz, bits(global triangle id))  id = position in (object list order, triangle
 //            (e2.xyz, bits(list index))               index) — restores the tie rule
-//   nodes: 4 float4 per INNER node holding BOTH children's boxes, so one 64-byte load per level:
-//            (L.lo.x, L.lo.y, L.lo.z, L.hi.x) (L.hi.y, L.hi.z, R.lo.x, R.lo.y)
-//            (R.lo.z, R.hi.x, R.hi.y, R.hi.z) (bits(left ref), bits(right ref), _, _)
-//          child ref >= 0: inner node index; ref < 0: leaf, -(1 + first*4 + (count-1));
-//          an absent child has an inverted box (lo = +inf, hi = -inf) and is never entered.
+//   nodes: 6 float4 (96 B) per 8-WIDE inner node, child boxes quantized to 8 bits on the node's own box:
+//            (origin.xyz, bits(ex | ey<<8 | ez<<16))   cell size per axis = 2^(e-127)
+//            (lo.x[0..3], lo.x[4..7], lo.y[0..3], lo.y[4..7])   one byte per child
+//            (lo.z[0..3], lo.z[4..7], hi.x[0..3], hi.x[4..7])
+//            (hi.y[0..3], hi.y[4..7], hi.z[0..3], hi.z[4..7])
+//            (ref[0..3]) (ref[4..7])
+//          child box = origin + q*cell, lo rounded down / hi up, so it encloses the exact box.
+//          ref > 0: inner node index; ref < 0: leaf, -(1 + first*4 + (count-1)); ref == 0: no child.
 //          Node 0 is the root; a mesh of <= 4 triangles is a root with one leaf child.
-// Build: binned surface-area heuristic (16 bins per axis, median fallback), leaves of <= 4
-// triangles — deterministic.  Bounds are exact (float min/max of the float vertices); the
+// Build: binary binned surface-area heuristic (16 bins per axis, median fallback), leaves of <= 4
+// triangles, then collapsed to 8 children per node — deterministic.  Bounds are exact (float min/max of the float vertices); the
 // kernel pads them per ray (see closest_hit) so that the box filter is conservative with
 // respect to the rounding of the triangle test.
 #pragma once
@@ -203,54 +206,111 @@ inline void build_mesh_image(const srt_object* objects, size_t count, const std:
     out.max_depth = 0;
     Rec::build(nodes, tris, 0, (int)tris.size(), 1, out.max_depth);
 
-    // second pass: inner nodes that carry both children's boxes
+    // second pass: collapse the binary tree into 8-wide nodes.  A wide node starts with the two
+    // children of a binary inner node and keeps replacing its largest (surface area) inner child
+    // by that child's two children until it has 8 children or only leaves.
     struct Wide {
-        float box[2][6];
-        int32_t ref[2];
+        int child[8];  // binary node indices
+        int n;
     };
     std::vector<Wide> wide;
-    std::vector<int> wide_index(nodes.size(), -1);
-    for (size_t k = 0; k < nodes.size(); ++k)
-        if (nodes[k].b <= 0) {  // inner
-            wide_index[k] = (int)wide.size();
-            wide.push_back(Wide());
-        }
-    auto ref_of = [&](int node) -> int32_t {
-        if (nodes[node].b > 0) return -(1 + nodes[node].a * 4 + (nodes[node].b - 1));
-        return wide_index[node];
+    auto area_of = [&](int k) {
+        const double dx = (double)nodes[k].hi[0] - nodes[k].lo[0], dy = (double)nodes[k].hi[1] - nodes[k].lo[1],
+                     dz = (double)nodes[k].hi[2] - nodes[k].lo[2];
+        return 2.0 * (dx * dy + dy * dz + dz * dx);
     };
-    auto put_box = [&](float* dst, int node) {
-        for (int ax = 0; ax < 3; ++ax) {
-            dst[ax] = nodes[node].lo[ax];
-            dst[3 + ax] = nodes[node].hi[ax];
-        }
-    };
-    if (wide.empty()) {  // the whole mesh is one leaf
+    std::vector<int> wide_of(nodes.size(), -1);  // binary inner node -> wide node that expands it
+    std::vector<std::pair<int, int>> todo;       // (binary node, depth), breadth-first so that siblings are neighbours
+    if (nodes[0].b > 0) {                        // the whole mesh is one leaf
         Wide w;
-        put_box(w.box[0], 0);
-        for (int q = 0; q < 3; ++q) w.box[1][q] = INFINITY, w.box[1][3 + q] = -INFINITY;
-        w.ref[0] = ref_of(0);
-        w.ref[1] = -1;
+        w.child[0] = 0;
+        w.n = 1;
         wide.push_back(w);
+        out.max_depth = 1;
     } else {
-        for (size_t k = 0; k < nodes.size(); ++k) {
-            if (nodes[k].b > 0) continue;
-            Wide& w = wide[(size_t)wide_index[k]];
-            const int left = (int)k + 1, right = nodes[k].a;
-            put_box(w.box[0], left);
-            put_box(w.box[1], right);
-            w.ref[0] = ref_of(left);
-            w.ref[1] = ref_of(right);
+        wide_of[0] = 0;
+        wide.push_back(Wide());
+        todo.push_back({0, 1});
+        out.max_depth = 1;
+        for (size_t q = 0; q < todo.size(); ++q) {
+            const int k = todo[q].first, depth = todo[q].second;
+            Wide w;
+            w.child[0] = k + 1;
+            w.child[1] = nodes[k].a;
+            w.n = 2;
+            while (w.n < 8) {
+                int pick = -1;
+                double pa = -1.0;
+                for (int c = 0; c < w.n; ++c)
+                    if (nodes[w.child[c]].b <= 0 && area_of(w.child[c]) > pa) pa = area_of(w.child[c]), pick = c;
+                if (pick < 0) break;
+                const int inner = w.child[pick];
+                for (int c = w.n; c > pick + 1; --c) w.child[c] = w.child[c - 1];  // keep the spatial order
+                w.child[pick] = inner + 1;
+                w.child[pick + 1] = nodes[inner].a;
+                ++w.n;
+            }
+            for (int c = 0; c < w.n; ++c)
+                if (nodes[w.child[c]].b <= 0) {
+                    wide_of[w.child[c]] = (int)wide.size();
+                    wide.push_back(Wide());
+                    todo.push_back({w.child[c], depth + 1});
+                    out.max_depth = std::max(out.max_depth, depth + 1);
+                }
+            wide[(size_t)wide_of[k]] = w;
         }
     }
+    // quantize: child boxes on a 256^3 grid spanned by the node's own box.  origin = node.lo (float),
+    // cell = 2^e per axis (the smallest power of two with 255 cells >= extent); lo is rounded down,
+    // hi up, in exact double arithmetic, so  origin + q*cell  (as real numbers) encloses the child.
     out.n_nodes = (int)wide.size();
-    out.nodes.resize(wide.size() * 4);
+    out.nodes.assign(wide.size() * 6, make_float4(0, 0, 0, 0));
     for (size_t k = 0; k < wide.size(); ++k) {
         const Wide& w = wide[k];
-        out.nodes[4 * k] = make_float4(w.box[0][0], w.box[0][1], w.box[0][2], w.box[0][3]);
-        out.nodes[4 * k + 1] = make_float4(w.box[0][4], w.box[0][5], w.box[1][0], w.box[1][1]);
-        out.nodes[4 * k + 2] = make_float4(w.box[1][2], w.box[1][3], w.box[1][4], w.box[1][5]);
-        out.nodes[4 * k + 3] = make_float4(bits_of(w.ref[0]), bits_of(w.ref[1]), 0.0f, 0.0f);
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int c = 0; c < w.n; ++c)
+            for (int ax = 0; ax < 3; ++ax) {
+                lo[ax] = std::min(lo[ax], nodes[w.child[c]].lo[ax]);
+                hi[ax] = std::max(hi[ax], nodes[w.child[c]].hi[ax]);
+            }
+        uint32_t expo[3];
+        double cell[3];
+        for (int ax = 0; ax < 3; ++ax) {
+            const double ext = (double)hi[ax] - (double)lo[ax];
+            int e = -126;
+            while (e < 127 && ldexp(255.0, e) < ext) ++e;
+            expo[ax] = (uint32_t)(e + 127);
+            cell[ax] = ldexp(1.0, e);
+        }
+        uint8_t q[6][8];
+        int32_t ref[8];
+        for (int c = 0; c < 8; ++c) {
+            if (c >= w.n) {  // absent child: inverted box, ref 0 (the root is nobody's child)
+                for (int ax = 0; ax < 3; ++ax) q[ax][c] = 255, q[3 + ax][c] = 0;
+                ref[c] = 0;
+                continue;
+            }
+            const Node& ch = nodes[w.child[c]];
+            for (int ax = 0; ax < 3; ++ax) {
+                double ql = floor(((double)ch.lo[ax] - (double)lo[ax]) / cell[ax]);
+                double qh = ceil(((double)ch.hi[ax] - (double)lo[ax]) / cell[ax]);
+                ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
+                qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+                q[ax][c] = (uint8_t)ql;
+                q[3 + ax][c] = (uint8_t)qh;
+            }
+            ref[c] = ch.b > 0 ? -(1 + ch.a * 4 + (ch.b - 1)) : wide_of[w.child[c]];
+        }
+        auto pack4 = [&](int row, int first) {
+            return bits_of((int32_t)((uint32_t)q[row][first] | ((uint32_t)q[row][first + 1] << 8) | ((uint32_t)q[row][first + 2] << 16) |
+                                     ((uint32_t)q[row][first + 3] << 24)));
+        };
+        out.nodes[6 * k + 0] = make_float4(lo[0], lo[1], lo[2], bits_of((int32_t)(expo[0] | (expo[1] << 8) | (expo[2] << 16))));
+        out.nodes[6 * k + 1] = make_float4(pack4(0, 0), pack4(0, 4), pack4(1, 0), pack4(1, 4));  // lo.x[0..7], lo.y[0..7]
+        out.nodes[6 * k + 2] = make_float4(pack4(2, 0), pack4(2, 4), pack4(3, 0), pack4(3, 4));  // lo.z, hi.x
+        out.nodes[6 * k + 3] = make_float4(pack4(4, 0), pack4(4, 4), pack4(5, 0), pack4(5, 4));  // hi.y, hi.z
+        out.nodes[6 * k + 4] = make_float4(bits_of(ref[0]), bits_of(ref[1]), bits_of(ref[2]), bits_of(ref[3]));
+        out.nodes[6 * k + 5] = make_float4(bits_of(ref[4]), bits_of(ref[5]), bits_of(ref[6]), bits_of(ref[7]));
     }
     out.tris.resize(tris.size() * 3);
     out.gidpos.assign(tris.size(), 0);
