@@ -24,8 +24,8 @@
 //         list, lanes pull items, fetch the ray with __shfl, run the EXACT arithmetic and merge
 //         through a 64-bit LDS atomicMin on (ordered distance, list index, primitive);
 //       - boxes: exact iq slab test, per-ray part hoisted;
-//       - EXTENSION, triangle meshes: wave-cooperative BVH traversal (LDS LIFO of (ray, node)
-//         items), srt_mesh_bvh.h.
+//       - EXTENSION, triangle meshes: wave-cooperative traversal of an 8-wide quantized BVH (LDS
+//         LIFO of (ray, node) items, 8 lanes per item when few wait), srt_mesh_bvh.h.
 //   * counter-based RNG keyed (seed, absolute pixel, sample, draw#): include/srt_defs.h.
 //
 // Bit-exactness rules (the file is compiled with -ffp-contract=off; hipcc's default
