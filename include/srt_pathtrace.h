@@ -162,7 +162,9 @@ int srt_destroy(srt_context* ctx);
 const char* srt_last_error(const srt_context* ctx);
 
 /* ---- state the worker reads ---------------------------------------------------- */
-/* Replaces ObjectsToRender (Raytracer.cpp:61,293). Copies; count may be 0. */
+/* Replaces ObjectsToRender (Raytracer.cpp:61,293). Copies; count may be 0 and at most 32767
+ * (SRT_ERR_INVALID_ARG beyond).  Scenes of up to ~2000 primitives are staged in LDS; larger ones are
+ * read from HBM by a slower instantiation of the same kernel (same results). */
 int srt_set_scene(srt_context* ctx, const srt_object* objects, size_t count);
 /* EXTENSION: mesh geometry referenced by SRT_OBJ_MESH objects.  Call BEFORE srt_set_scene; copies. */
 int srt_set_meshes(srt_context* ctx, const srt_mesh* meshes, size_t count);

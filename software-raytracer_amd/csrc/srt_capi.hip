@@ -68,6 +68,8 @@ struct srt_context {
     uint64_t pending_samples = 0;
     bool count_rays = false;
     int lds_limit_bytes = 64 * 1024;
+    bool scene_in_lds[2] = {true, true};  // per scene image: does it fit into LDS next to the scratch?
+    bool pick_in_lds[2] = {true, true};
     int variant = -1;  // >= 0 overrides SRT_KERNEL (set through srt_debug_set_variant)
 
     char error[512] = "";
@@ -222,11 +224,16 @@ int srt_set_scene(srt_context* ctx, const srt_object* objects, size_t count) {
     for (int v = 0; v < 2; ++v) {
         // with meshes both images are the same one, so that primitive ids agree with the BVH
         srt::SceneLayout L = srt::build_scene_image(objects, count, (v == 0 || has_mesh) && !no_cluster, ctx->h_scene[v]);
-        if ((size_t)L.total_vec4 * sizeof(float4) + srt::WG_SCRATCH_BYTES + (has_mesh ? srt::WG_MESH_SCRATCH_BYTES : 0) > (size_t)ctx->lds_limit_bytes ||
-            count >= 32768)
-            return fail(ctx, SRT_ERR_INVALID_ARG,
-                        "srt_set_scene: %d spheres + %d boxes need %zu B of LDS, limit %d B (tile streaming not built yet)",
-                        L.n_spheres, L.nb, (size_t)L.total_vec4 * sizeof(float4), ctx->lds_limit_bytes);
+        // hit_key packs the list index in 15 bits and the primitive id in 16
+        if (count >= 32768 || L.nsT + L.nb + L.nm >= 65536)
+            return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: %zu objects (%d sphere slots + %d boxes + %d meshes) exceed the 32767-object limit",
+                        count, L.nsT, L.nb, L.nm);
+        // an image that does not fit into LDS next to the per-wave scratch stays in HBM (slower kernel
+        // instantiation, same bits); the pick kernel runs one wave, so it is judged separately
+        const size_t image_bytes = (size_t)L.total_vec4 * sizeof(float4);
+        const size_t mesh_scratch = has_mesh ? (size_t)srt::WG_MESH_SCRATCH_BYTES : 0;
+        ctx->scene_in_lds[v] = image_bytes + srt::WG_SCRATCH_BYTES + mesh_scratch <= (size_t)ctx->lds_limit_bytes;
+        ctx->pick_in_lds[v] = image_bytes + srt::WAVE_SCRATCH_BYTES + srt::MESH_WAVE_BYTES <= (size_t)ctx->lds_limit_bytes;
         if (ctx->h_scene[v].size() > ctx->scene_capacity_vec4[v] || !ctx->d_scene[v]) {
             if (ctx->d_scene[v]) SRT_HIP(ctx, hipFree(ctx->d_scene[v]));
             ctx->d_scene[v] = nullptr;
@@ -327,7 +334,7 @@ int srt_device_accumulator(srt_context* ctx, void** d_ptr) {
 
 }  // extern "C"
 
-static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt::KernelParams& K, size_t& lds_bytes, int& use) {
+static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt::KernelParams& K, size_t& lds_bytes, int& use, int& img) {
     const int W = ctx->width, H = ctx->height;
     memset(&K, 0, sizeof K);
     const srt_camera& c = ctx->camera.cam;
@@ -365,7 +372,7 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
         return v ? atoi(v) : 0;
     }();
     use = ctx->variant >= 0 ? ctx->variant : variant;
-    const int img = (use == 2) ? 1 : 0;  // variant 2: plain brute-force image
+    img = (use == 2) ? 1 : 0;  // variant 2: plain brute-force image
     K.mesh_defer = use >= 100 ? use - 100 : 16;  // variants 100 + n: mesh phases wait for n rays
     const srt::SceneLayout& SL = ctx->layout[img];
     K.nu4 = SL.nu4;
@@ -389,7 +396,7 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
     K.framebuffer = ctx->d_fb;
     K.ray_counter = ctx->d_rays;
 
-    lds_bytes = (size_t)(SL.total_vec4 > 0 ? SL.total_vec4 : 1) * sizeof(float4) + srt::WG_SCRATCH_BYTES +
+    lds_bytes = (ctx->scene_in_lds[img] ? (size_t)(SL.total_vec4 > 0 ? SL.total_vec4 : 1) * sizeof(float4) : 0) + srt::WG_SCRATCH_BYTES +
                 (ctx->mesh_image.n_tris > 0 ? srt::WG_MESH_SCRATCH_BYTES : 0);
     return SRT_OK;
 }
@@ -416,7 +423,8 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     srt::KernelParams K;
     size_t lds_bytes = 0;
     int use = 0;
-    fill_kernel_params(ctx, p, K, lds_bytes, use);
+    int img = 0;
+    fill_kernel_params(ctx, p, K, lds_bytes, use, img);
     ctx->count_rays = (p->flags & SRT_RENDER_COUNT_RAYS) != 0;
     if (ctx->count_rays) SRT_HIP(ctx, hipMemsetAsync(ctx->d_rays, 0, sizeof(unsigned long long), ctx->stream));
 
@@ -424,7 +432,11 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     dim3 block(srt::WG_THREADS);
     SRT_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     // variants are a development aid for in-process A/B timing; all are bit-identical
-    if (K.n_tris > 0)  // EXTENSION: scenes with triangle meshes use the BVH-enabled instantiation
+    if (!ctx->scene_in_lds[img] && K.n_tris > 0)  // scene image too large for LDS: read it from HBM/L2
+        hipLaunchKernelGGL((srt::pathtrace_kernel<3, true, false>), grid, block, lds_bytes, ctx->stream, K);
+    else if (!ctx->scene_in_lds[img])
+        hipLaunchKernelGGL((srt::pathtrace_kernel<4, false, false>), grid, block, lds_bytes, ctx->stream, K);
+    else if (K.n_tris > 0)  // EXTENSION: scenes with triangle meshes use the BVH-enabled instantiation
         hipLaunchKernelGGL((srt::pathtrace_kernel<3, true>), grid, block, lds_bytes, ctx->stream, K);
     else if (use == 1)
         hipLaunchKernelGGL((srt::pathtrace_kernel<5, false>), grid, block, lds_bytes, ctx->stream, K);
@@ -477,9 +489,15 @@ int srt_pick(srt_context* ctx, int x, int y, int* object_index) {
     srt::KernelParams K;
     size_t lds_bytes = 0;
     int use = 0;
-    fill_kernel_params(ctx, &p, K, lds_bytes, use);
+    int img = 0;
+    fill_kernel_params(ctx, &p, K, lds_bytes, use, img);
     int* d_out = ctx->d_pick;
-    hipLaunchKernelGGL(srt::pick_kernel, dim3(1), dim3(64), lds_bytes, ctx->stream, K, x, y, d_out);
+    // one wave: image (if it fits) + one wave's scratch + one wave's mesh queues
+    const size_t image_bytes = (size_t)(K.scene_vec4 > 0 ? K.scene_vec4 : 1) * sizeof(float4);
+    if (ctx->pick_in_lds[img])
+        hipLaunchKernelGGL(srt::pick_kernel<true>, dim3(1), dim3(64), image_bytes + srt::WAVE_SCRATCH_BYTES + srt::MESH_WAVE_BYTES, ctx->stream, K, x, y, d_out);
+    else
+        hipLaunchKernelGGL(srt::pick_kernel<false>, dim3(1), dim3(64), (size_t)(srt::WAVE_SCRATCH_BYTES + srt::MESH_WAVE_BYTES), ctx->stream, K, x, y, d_out);
     SRT_HIP(ctx, hipGetLastError());
     int idx[4] = {-1, 0, 0, 0};
     SRT_HIP(ctx, hipMemcpyAsync(idx, d_out, sizeof idx, hipMemcpyDeviceToHost, ctx->stream));

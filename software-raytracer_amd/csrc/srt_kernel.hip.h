@@ -365,7 +365,8 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                 const bool win = valid & ((dist < best) | (tie & (S.order(nsT + j) < ob)));
                 best = win ? dist : best;
                 bp = win ? nsT + j : bp;
-                bt1 = win ? t1 : bt1;
+                // component-wise: a whole-struct select is lowered to a pointer select + copies through scratch
+                bt1 = v3(win ? t1.x : bt1.x, win ? t1.y : bt1.y, win ? t1.z : bt1.z);
             }
         }
     }
@@ -664,18 +665,34 @@ __device__ __forceinline__ uint32_t pack_channel(float v) {  // Common.hpp:190-2
     return (uint32_t)(uint8_t)s;
 }
 
-template <int MIN_WAVES, bool MESH>
+// Per-wave view of the workgroup's LDS: [scene image (SCENE_LDS only)] [waves x WAVE_SCRATCH_BYTES]
+// [waves x MESH_WAVE_BYTES (mesh kernel only)].  SCENE_LDS == false is the fallback for scene images
+// that do not fit next to the scratch (thousands of analytic primitives): the same image is then read
+// from HBM/L2 through the same accessors — slower per test, same arithmetic, same bits.
+template <bool SCENE_LDS>
+__device__ __forceinline__ Lds make_lds(const KernelParams& P, float4* lds, int waves, int wave) {
+    char* wg = reinterpret_cast<char*>(lds + (SCENE_LDS ? P.scene_vec4 : 0));
+    char* scratch = wg + wave * WAVE_SCRATCH_BYTES;
+    const float4* image;
+    if constexpr (SCENE_LDS)
+        image = lds;
+    else
+        image = P.scene;
+    return Lds{image, P.nu4, P.nc, P.K, P.nsT, P.nb, P.off_bounds, P.off_box, P.off_mat,
+               reinterpret_cast<unsigned long long*>(scratch), reinterpret_cast<unsigned short*>(scratch + 64 * 8),
+               reinterpret_cast<float*>(scratch + 64 * 8 + WORK_MAX * 2),
+               reinterpret_cast<float4*>(scratch + 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4),
+               reinterpret_cast<unsigned*>(wg + waves * WAVE_SCRATCH_BYTES + wave * MESH_WAVE_BYTES)};
+}
+
+template <int MIN_WAVES, bool MESH, bool SCENE_LDS = true>
 __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const KernelParams P) {
     extern __shared__ float4 lds_scene[];
-    // ---- stage the scene image into LDS (coalesced 16-byte loads) -----------------
-    for (int i = threadIdx.x; i < P.scene_vec4; i += WG_THREADS) lds_scene[i] = P.scene[i];
-    __syncthreads();
-    char* scratch = reinterpret_cast<char*>(lds_scene + P.scene_vec4) + (threadIdx.x >> 6) * WAVE_SCRATCH_BYTES;
-    Lds S{lds_scene, P.nu4, P.nc, P.K, P.nsT, P.nb, P.off_bounds, P.off_box, P.off_mat,
-          reinterpret_cast<unsigned long long*>(scratch), reinterpret_cast<unsigned short*>(scratch + 64 * 8),
-          reinterpret_cast<float*>(scratch + 64 * 8 + WORK_MAX * 2),
-          reinterpret_cast<float4*>(scratch + 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4),
-          reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds_scene + P.scene_vec4) + WG_SCRATCH_BYTES + (threadIdx.x >> 6) * MESH_WAVE_BYTES)};
+    if constexpr (SCENE_LDS) {  // stage the scene image into LDS (coalesced 16-byte loads)
+        for (int i = threadIdx.x; i < P.scene_vec4; i += WG_THREADS) lds_scene[i] = P.scene[i];
+        __syncthreads();
+    }
+    const Lds S = make_lds<SCENE_LDS>(P, lds_scene, WG_TILES_X * WG_TILES_Y, threadIdx.x >> 6);
 
     // ---- pixel of this lane ----------------------------------------------------------
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -971,16 +988,14 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
 }
 
 // Picking (Raytracer.cpp:525-541): one wave, every lane traces the same ray.
+template <bool SCENE_LDS>
 __global__ void __launch_bounds__(64) pick_kernel(const KernelParams P, int px, int py, int* out_index) {
     extern __shared__ float4 lds_scene[];
-    for (int i = threadIdx.x; i < P.scene_vec4; i += 64) lds_scene[i] = P.scene[i];
-    __syncthreads();
-    char* scratch = reinterpret_cast<char*>(lds_scene + P.scene_vec4);
-    Lds S{lds_scene, P.nu4, P.nc, P.K, P.nsT, P.nb, P.off_bounds, P.off_box, P.off_mat,
-          reinterpret_cast<unsigned long long*>(scratch), reinterpret_cast<unsigned short*>(scratch + 64 * 8),
-          reinterpret_cast<float*>(scratch + 64 * 8 + WORK_MAX * 2),
-          reinterpret_cast<float4*>(scratch + 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4),
-          reinterpret_cast<unsigned*>(scratch + WG_SCRATCH_BYTES)};
+    if constexpr (SCENE_LDS) {
+        for (int i = threadIdx.x; i < P.scene_vec4; i += 64) lds_scene[i] = P.scene[i];
+        __syncthreads();
+    }
+    const Lds S = make_lds<SCENE_LDS>(P, lds_scene, 1, 0);
     float nX = ((float)px / (float)P.width) * 2 - 1;
     float nY = ((float)py / (float)P.height) * 2 - 1;
     V3 u = v3(P.right_rd[0] * nX, P.right_rd[1] * nX, P.right_rd[2] * nX);

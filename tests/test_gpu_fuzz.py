@@ -82,3 +82,50 @@ def test_random_scene_parity(srt, oracle, seed):
     assert np.array_equal(gacc.view(np.uint32), oacc.view(np.uint32)), (kind, n, int((gacc.view(np.uint32) != oacc.view(np.uint32)).any(-1).sum()))
     assert np.array_equal(pt.framebuffer(), ofb)
     pt.close()
+
+
+@pytest.mark.parametrize("with_mesh", [False, True])
+def test_scene_larger_than_lds(srt, oracle, with_mesh):
+    """3400 spheres + 60 boxes: the scene image (~220 KB) cannot sit in LDS, so the kernel reads it
+    from HBM through the same accessors (SCENE_LDS == false instantiation).  Same bits as the oracle,
+    rendering and picking."""
+    rng = np.random.default_rng(77)
+    objs = []
+    for _ in range(3400):
+        objs.append(dict(type=oracle.OBJ_SPHERE, position=tuple(float(v) for v in (rng.uniform(-6, 6), rng.uniform(-3, 3), rng.uniform(4, 16))),
+                         radius=float(rng.uniform(0.03, 0.25)) * (8.0 if rng.uniform() < 0.01 else 1.0),
+                         base=tuple(float(v) for v in rng.uniform(0, 1, 3)), emissive=tuple(float(v) for v in rng.uniform(0, 3, 3) * (rng.uniform() < 0.05)),
+                         specular_amount=float(rng.uniform(0, 1)), smoothness=float(rng.uniform(0, 1))))
+    for _ in range(60):
+        objs.append(dict(type=oracle.OBJ_BOX, position=tuple(float(v) for v in (rng.uniform(-6, 6), rng.uniform(-3, 3), rng.uniform(4, 16))),
+                         half_size=tuple(float(v) for v in rng.uniform(0.05, 0.5, 3)), base=tuple(float(v) for v in rng.uniform(0, 1, 3)),
+                         specular_amount=float(rng.uniform(0, 1)), smoothness=float(rng.uniform(0, 1))))
+    objs.append(dict(type=oracle.OBJ_SPHERE, position=(0.0, -1003.5, 8.0), radius=1000.0, base=(0.6, 0.6, 0.6)))
+    meshes = []
+    if with_mesh:
+        V, T = oracle.uv_sphere(0.8, 12, 16)
+        meshes.append((V, T))
+        objs.append(dict(type=oracle.OBJ_MESH, position=(0.3, 0.2, 3.0), mesh=0, base=(0.9, 0.5, 0.2), smoothness=0.3))
+    order = rng.permutation(len(objs))
+    objs = [objs[i] for i in order]
+    oarr, n = oracle.make_objects(objs)
+    marr, mn, keep = oracle.make_meshes(meshes)
+    w, h = 96, 64
+    cam = oracle.default_camera()
+    pt = srt.PathTracer(w, h)
+    pt.set_meshes(C.cast(marr, C.POINTER(srt.Mesh)), mn)
+    pt.set_scene(C.cast(oarr, C.POINTER(srt.Object)), n)
+    pt.set_camera(srt.Camera.from_buffer_copy(bytes(cam)))
+    kw = dict(spp=3, bounces=5, seed=11)
+    pt.render(count_rays=True, **kw)
+    ofb, oacc, orays = oracle.render(oarr, n, oracle.default_environment(), cam, w, h, meshes=(marr, mn) if mn else None, **kw)
+    assert pt.stats().rays == orays
+    assert np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32))
+    assert np.array_equal(pt.framebuffer(), ofb)
+    if not with_mesh:  # the oracle's closest-object probe is analytic only
+        d, nn, pp, t = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 3)(), C.c_float()
+        origin = (C.c_float * 3)(0, 0, 0)
+        for (x, y) in [(0, 0), (48, 32), (20, 10), (90, 60), (48, 5), (33, 33)]:
+            oracle.lib().srt_oracle_ray_direction(C.byref(cam), w, h, x, y, d)
+            assert pt.pick(x, y) == oracle.lib().srt_oracle_closest(oarr, n, origin, d, nn, pp, C.byref(t))
+    pt.close()

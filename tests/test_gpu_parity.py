@@ -75,11 +75,16 @@ def test_random_large_scenes(srt, oracle, nsph, nbox):
     pt.close()
 
 
-def test_scene_too_large_for_lds_is_rejected(srt, oracle):
+def test_object_count_limit(srt, oracle):
+    """The hit key holds the list index in 15 bits: 32768 objects are refused with a message, 4000 (an
+    image beyond LDS, served from HBM — see test_scene_larger_than_lds) are accepted."""
+    pt = srt.PathTracer(16, 16)
     objs = [dict(type=oracle.OBJ_SPHERE, position=(i * 0.01, 0, 5), radius=0.01) for i in range(4000)]
     oarr, n = oracle.make_objects(objs)
-    pt = srt.PathTracer(16, 16)
+    pt.set_scene(C.cast(oarr, C.POINTER(srt.Object)), n)
+    objs = [dict(type=oracle.OBJ_NONE)] * 32768
+    oarr, n = oracle.make_objects(objs)
     with pytest.raises(srt.SrtError) as e:
         pt.set_scene(C.cast(oarr, C.POINTER(srt.Object)), n)
-    assert e.value.code == srt.capi.ERR_INVALID_ARG and "LDS" in str(e.value)
+    assert e.value.code == srt.capi.ERR_INVALID_ARG and "32767" in str(e.value)
     pt.close()
