@@ -575,6 +575,9 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                         batch = batch > 4 ? batch >> 2 : 1;
                     } else {
                         strict = true;  // cannot overflow: the host bounds 7 * depth + 8 by MESH_QN
+#ifdef SRT_STATS
+                        if (SRT_STATS == 1) SRT_STAT(7, 1);
+#endif
                     }
 #ifdef SRT_STATS
                     if (SRT_STATS == 1 && overflow) SRT_STAT(6, 1);

@@ -26,7 +26,7 @@ L.srt_debug_read_stats(out)
 pt.render(spp=a.spp, bounces=a.bounces, seed=0, count_rays=True)
 st = pt.stats()
 L.srt_debug_read_stats(out)
-names = ["mesh phases (waves)", "go lanes", "node rounds", "node items", "leaf rounds", "leaf items", "overflows", "fallback iters"]
+names = ["mesh phases (waves)", "go lanes", "node rounds", "node items", "leaf rounds", "leaf items", "overflows", "strict-mode entries"]
 for k, v in zip(names, out): print("%-22s %d" % (k, v))
 print("rays %d  kernel %.3f ms" % (st.rays, st.kernel_ms))
 if os.environ.get("SRT_STATS_MODE") == "2":

@@ -187,3 +187,33 @@ def test_config5_shape_4k_mixed_scene_properties(srt, oracle):
     assert np.array_equal(pt.framebuffer(), a)
     assert (a >> 24 == 0).all()
     pt.close()
+
+
+def test_triangle_pile_overflows_the_traversal_queues(srt, oracle):
+    """6000 large, nearly coincident triangles: every ray meets most boxes of the BVH, so the node and
+    leaf queues of the cooperative traversal overflow, batches are redone with fewer rays and a few
+    rays end up in strict depth-first mode (counters of a STATS=1 build: 94 overflows, 3 strict entries
+    for exactly this scene).  Result must still equal the brute-force oracle bit for bit."""
+    rng = np.random.default_rng(5)
+    nt = 6000
+    V = np.zeros((3 * nt, 3), np.float32)
+    base = np.array([[-2, -2, 0], [2, -2, 0], [0, 2, 0]], np.float32)
+    for k in range(nt):
+        V[3 * k:3 * k + 3] = base + rng.uniform(-0.3, 0.3, (3, 3)).astype(np.float32) + np.array([0, 0, rng.uniform(-0.5, 0.5)], np.float32)
+    T = np.arange(3 * nt, dtype=np.uint32).reshape(nt, 3)
+    objs = [dict(type=oracle.OBJ_MESH, position=(0.0, 0.0, 6.0), mesh=0, base=(0.8, 0.7, 0.6), smoothness=0.2),
+            dict(type=oracle.OBJ_SPHERE, position=(0.0, -1002.5, 6.0), radius=1000.0, base=(0.5, 0.5, 0.5))]
+    oarr, n = oracle.make_objects(objs)
+    marr, mn, keep = oracle.make_meshes([(V, T)])
+    w, h = 40, 30
+    pt = srt.PathTracer(w, h)
+    pt.set_meshes(C.cast(marr, C.POINTER(srt.Mesh)), mn)
+    pt.set_scene(C.cast(oarr, C.POINTER(srt.Object)), n)
+    pt.set_camera(srt.default_camera())
+    kw = dict(spp=2, bounces=3, seed=4)
+    pt.render(count_rays=True, **kw)
+    ofb, oacc, orays = oracle.render(oarr, n, oracle.default_environment(), oracle.default_camera(), w, h, meshes=(marr, mn), **kw)
+    assert pt.stats().rays == orays
+    assert np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32))
+    assert np.array_equal(pt.framebuffer(), ofb)
+    pt.close()
