@@ -10,6 +10,8 @@
  * dialect).  This oracle is therefore a line-by-line restatement of
  * the reference's arithmetic, pinned only by hand-derived analytic vectors and by
  * the scene generator recorded in Raytracer.cpp:299-325 — not by reference output.
+ * (The one part of the reference that does build here, its vendored JSON library, pins
+ * the scene wire format instead: ref_json_harness.cpp, tests/test_json_vs_reference.py.)
  */
 #ifndef SRT_ORACLE_H
 #define SRT_ORACLE_H

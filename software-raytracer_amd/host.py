@@ -16,7 +16,7 @@ EXPORTS = [
     "srt_host_scene_load", "srt_host_scene_new", "srt_host_scene_free", "srt_host_scene_count",
     "srt_host_scene_objects", "srt_host_scene_mesh_count", "srt_host_scene_mesh", "srt_host_scene_error", "srt_host_scene_name", "srt_host_scene_object_name",
     "srt_host_scene_add", "srt_host_scene_remove", "srt_host_scene_save_as", "srt_host_scene_dump",
-    "srt_host_format_double", "srt_host_rotate_about_axis", "srt_host_last_error",
+    "srt_host_format_double", "srt_host_json_roundtrip", "srt_host_rotate_about_axis", "srt_host_last_error",
     "srt_host_renderer_create", "srt_host_renderer_destroy", "srt_host_renderer_set_scene",
     "srt_host_renderer_set_band", "srt_host_renderer_settings", "srt_host_renderer_set_camera",
     "srt_host_renderer_invalidate", "srt_host_renderer_mode", "srt_host_renderer_pick", "srt_host_renderer_render_frame", "srt_host_renderer_render_samples",
@@ -67,6 +67,8 @@ def load_library():
     L.srt_host_scene_save_as.restype = None
     L.srt_host_format_double.argtypes = [C.c_double, C.c_char_p, C.c_size_t]
     L.srt_host_format_double.restype = C.c_size_t
+    L.srt_host_json_roundtrip.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
+    L.srt_host_json_roundtrip.restype = C.c_size_t
     L.srt_host_rotate_about_axis.argtypes = [C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float)]
     L.srt_host_rotate_about_axis.restype = None
     L.srt_host_last_error.restype = C.c_char_p
@@ -166,6 +168,17 @@ def format_double(v):
     buf = C.create_string_buffer(64)
     load_library().srt_host_format_double(float(v), buf, 64)
     return buf.value.decode()
+
+
+def json_roundtrip(text, indent=4):
+    """Json::parse + dump(indent) of the host JSON code; None on a parse error."""
+    data = text.encode() if isinstance(text, str) else bytes(text)
+    cap = 8 * len(data) + 1024
+    buf = C.create_string_buffer(cap)
+    n = load_library().srt_host_json_roundtrip(data, indent, buf, cap)
+    if n == C.c_size_t(-1).value:
+        return None
+    return buf.value.decode("utf-8", "surrogateescape")
 
 
 def rotate_about_axis(basis9, angle, axis):

@@ -9,6 +9,8 @@
 
 using namespace srt_host;
 
+static thread_local std::string g_err;
+
 extern "C" {
 
 struct srt_host_scene {
@@ -75,6 +77,22 @@ const char* srt_host_scene_dump(srt_host_scene* s) {
     return s->dump.c_str();
 }
 // Json::format_double, exposed for writer tests
+// Json::parse + dump(indent) of an arbitrary document (differential tests against the reference's
+// nlohmann/json).  Returns the length written (truncated to cap - 1), or (size_t)-1 on a parse error.
+size_t srt_host_json_roundtrip(const char* text, int indent, char* out, size_t cap) {
+    try {
+        std::string t = Json::parse(text ? text : "").dump(indent);
+        if (cap) {
+            std::strncpy(out, t.c_str(), cap - 1);
+            out[cap - 1] = 0;
+        }
+        return t.size();
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return (size_t)-1;
+    }
+}
+
 size_t srt_host_format_double(double v, char* out, size_t cap) {
     std::string t = Json::format_double(v);
     if (cap) {
@@ -105,7 +123,6 @@ struct srt_host_renderer {
     std::string error;
 };
 
-static thread_local std::string g_err;
 const char* srt_host_last_error() { return g_err.c_str(); }
 
 srt_host_renderer* srt_host_renderer_create(int device, int width, int height) {

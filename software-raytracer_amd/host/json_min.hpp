@@ -11,6 +11,7 @@
 #pragma once
 
 #include <charconv>
+#include <cstdlib>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -454,6 +455,27 @@ class Json {
                 if (c < 0x20) fail("control character in string");
                 if (c != '\\') {
                     out.push_back((char)c);
+                    if (c >= 0x80) {
+                        // well-formed UTF-8 only, like nlohmann's lexer (the reference's Scene::Load
+                        // rejects the whole file otherwise): lead byte -> allowed range of the 2nd byte
+                        int more;
+                        unsigned char lo = 0x80, hi = 0xBF;
+                        if (c >= 0xC2 && c <= 0xDF) more = 1;
+                        else if (c == 0xE0) more = 2, lo = 0xA0;
+                        else if ((c >= 0xE1 && c <= 0xEC) || c == 0xEE || c == 0xEF) more = 2;
+                        else if (c == 0xED) more = 2, hi = 0x9F;
+                        else if (c == 0xF0) more = 3, lo = 0x90;
+                        else if (c >= 0xF1 && c <= 0xF3) more = 3;
+                        else if (c == 0xF4) more = 3, hi = 0x8F;
+                        else fail("invalid UTF-8 in string");
+                        for (int k = 0; k < more; ++k) {
+                            if (cur == end) fail("invalid UTF-8 in string");
+                            const unsigned char t = (unsigned char)*cur;
+                            if (t < (k == 0 ? lo : 0x80) || t > (k == 0 ? hi : 0xBF)) fail("invalid UTF-8 in string");
+                            out.push_back((char)t);
+                            ++cur;
+                        }
+                    }
                     continue;
                 }
                 if (cur == end) fail("unterminated escape");
@@ -525,7 +547,13 @@ class Json {
             }
             double d = 0;
             auto r = std::from_chars(s, cur, d);
-            if (r.ec == std::errc::result_out_of_range) fail("number overflow");
+            if (r.ec == std::errc::result_out_of_range) {
+                // nlohmann (strtod, then !isfinite -> error) rejects overflow but takes an underflow
+                // as the (possibly zero or subnormal) value it rounds to
+                d = std::strtod(std::string(s, cur).c_str(), nullptr);
+                if (!std::isfinite(d)) fail("number overflow");
+                return Json(d);
+            }
             if (r.ec != std::errc() || r.ptr != cur) fail("bad number");
             return Json(d);
         }
