@@ -218,6 +218,9 @@ int srt_set_scene(srt_context* ctx, const srt_object* objects, size_t count) {
     }
     // the previous upload may still be in flight from h_scene
     SRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // from here on the context holds no scene until this call completes: a failure below must not leave
+    // a half-replaced one (new image, freed BVH) for srt_render to launch on
+    ctx->scene_set = false;
     static const bool no_cluster = getenv("SRT_NO_CLUSTER") != nullptr;
     bool has_mesh = false;
     for (size_t i = 0; i < count; ++i) has_mesh = has_mesh || objects[i].type == SRT_OBJ_MESH;

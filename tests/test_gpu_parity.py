@@ -87,4 +87,9 @@ def test_object_count_limit(srt, oracle):
     with pytest.raises(srt.SrtError) as e:
         pt.set_scene(C.cast(oarr, C.POINTER(srt.Object)), n)
     assert e.value.code == srt.capi.ERR_INVALID_ARG and "32767" in str(e.value)
+    # a failed srt_set_scene leaves the context without a scene, not with a half-replaced one
+    pt.set_camera(srt.default_camera())
+    with pytest.raises(srt.SrtError) as e:
+        pt.render(spp=1, bounces=1, seed=0)
+    assert e.value.code == srt.capi.ERR_STATE
     pt.close()
