@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <exception>
 #include <new>
 #include <vector>
 
@@ -203,7 +204,7 @@ int srt_destroy(srt_context* ctx) {
     return SRT_OK;
 }
 
-int srt_set_scene(srt_context* ctx, const srt_object* objects, size_t count) {
+static int set_scene_impl(srt_context* ctx, const srt_object* objects, size_t count) {
     if (!ctx) return SRT_ERR_INVALID_ARG;
     if (count && !objects) return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: objects is NULL");
     if (count > 0x3fffffff) return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: too many objects");
@@ -277,7 +278,20 @@ int srt_set_scene(srt_context* ctx, const srt_object* objects, size_t count) {
     return SRT_OK;
 }
 
-int srt_set_meshes(srt_context* ctx, const srt_mesh* meshes, size_t count) {
+// Host-side allocation failures (std::bad_alloc from the image / BVH builders) must not cross the C boundary.
+int srt_set_scene(srt_context* ctx, const srt_object* objects, size_t count) {
+    try {
+        return set_scene_impl(ctx, objects, count);
+    } catch (const std::bad_alloc&) {
+        if (ctx) ctx->scene_set = false;
+        return fail(ctx, SRT_ERR_OOM, "srt_set_scene: host allocation failed");
+    } catch (const std::exception& e) {
+        if (ctx) ctx->scene_set = false;
+        return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: %s", e.what());
+    }
+}
+
+static int set_meshes_impl(srt_context* ctx, const srt_mesh* meshes, size_t count) {
     if (!ctx) return SRT_ERR_INVALID_ARG;
     if (count && !meshes) return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_meshes: meshes is NULL");
     std::vector<srt::HostMesh> copy(count);
@@ -291,6 +305,16 @@ int srt_set_meshes(srt_context* ctx, const srt_mesh* meshes, size_t count) {
     }
     ctx->meshes.swap(copy);
     return SRT_OK;
+}
+
+int srt_set_meshes(srt_context* ctx, const srt_mesh* meshes, size_t count) {
+    try {
+        return set_meshes_impl(ctx, meshes, count);
+    } catch (const std::bad_alloc&) {
+        return fail(ctx, SRT_ERR_OOM, "srt_set_meshes: host allocation failed");
+    } catch (const std::exception& e) {
+        return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_meshes: %s", e.what());
+    }
 }
 
 int srt_set_environment(srt_context* ctx, const srt_environment* env) {
