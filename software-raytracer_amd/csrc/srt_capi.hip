@@ -69,6 +69,7 @@ struct srt_context {
     uint64_t pending_samples = 0;
     bool count_rays = false;
     int lds_limit_bytes = 64 * 1024;
+    int cu_count = 256;
     bool scene_in_lds[2] = {true, true};  // per scene image: does it fit into LDS next to the scratch?
     bool pick_in_lds[2] = {true, true};
     int variant = -1;  // >= 0 overrides SRT_KERNEL (set through srt_debug_set_variant)
@@ -180,6 +181,8 @@ int srt_create(int device, int width, int height, srt_context** out) {
     int lds = 0;
     if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0)
         ctx->lds_limit_bytes = lds;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->cu_count = cus;
     *out = ctx;
     return SRT_OK;
 }
@@ -455,22 +458,42 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     ctx->count_rays = (p->flags & SRT_RENDER_COUNT_RAYS) != 0;
     if (ctx->count_rays) SRT_HIP(ctx, hipMemsetAsync(ctx->d_rays, 0, sizeof(unsigned long long), ctx->stream));
 
-    dim3 grid((unsigned)((W + srt::WG_W - 1) / srt::WG_W), (unsigned)((K.rows + srt::WG_H - 1) / srt::WG_H));
+    // Tile height: with few rows and many samples per pixel (a narrow stripe of a multi-GPU frame) 8-row
+    // tiles give too few workgroups to fill 256 CUs x 4 resident workgroups and leave nothing to balance
+    // the tail with; halve the tile (twice the workgroups, same lanes at work in each wave's path pool)
+    // until there are about four rounds of workgroups.  Results do not depend on the tiling.
+    static const int tile_env = [] {
+        const char* v = getenv("SRT_TILE_H");
+        return v ? atoi(v) : 0;
+    }();
+    int tile_h = srt::TILE_H;
+    const long long wg_x = (W + srt::WG_W - 1) / srt::WG_W;
+    const long long want = 15LL * ctx->cu_count;  // ~4 rounds of the 4 workgroups a CU holds; measured on bands of 30..400 rows
+    while (tile_h > 1 && p->sample_count >= 16 && wg_x * ((K.rows + tile_h * srt::WG_TILES_Y - 1) / (tile_h * srt::WG_TILES_Y)) < want) tile_h >>= 1;
+    if (tile_env == 8 || tile_env == 4 || tile_env == 2 || tile_env == 1) tile_h = tile_env;
+    K.tile_h = tile_h;
+    dim3 grid((unsigned)wg_x, (unsigned)((K.rows + tile_h * srt::WG_TILES_Y - 1) / (tile_h * srt::WG_TILES_Y)));
     dim3 block(srt::WG_THREADS);
     SRT_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
-    // variants are a development aid for in-process A/B timing; all are bit-identical
-    if (!ctx->scene_in_lds[img] && K.n_tris > 0)  // scene image too large for LDS: read it from HBM/L2
-        hipLaunchKernelGGL((srt::pathtrace_kernel<3, true, false>), grid, block, lds_bytes, ctx->stream, K);
-    else if (!ctx->scene_in_lds[img])
-        hipLaunchKernelGGL((srt::pathtrace_kernel<4, false, false>), grid, block, lds_bytes, ctx->stream, K);
-    else if (K.n_tris > 0)  // EXTENSION: scenes with triangle meshes use the BVH-enabled instantiation
-        hipLaunchKernelGGL((srt::pathtrace_kernel<3, true>), grid, block, lds_bytes, ctx->stream, K);
-    else if (use == 1)
+    // instantiation: mesh or not, scene image in LDS or HBM, small tiles (multi-sample hand-out) or full
+    // ones; variants 1 / 3 are a development aid for in-process A/B timing.  All are bit-identical.
+    const bool in_lds = ctx->scene_in_lds[img], multi = tile_h < srt::TILE_H;
+    auto launch = [&](auto k_lds, auto k_lds_multi, auto k_hbm, auto k_hbm_multi) {
+        if (in_lds && !multi) hipLaunchKernelGGL(k_lds, grid, block, lds_bytes, ctx->stream, K);
+        else if (in_lds) hipLaunchKernelGGL(k_lds_multi, grid, block, lds_bytes, ctx->stream, K);
+        else if (!multi) hipLaunchKernelGGL(k_hbm, grid, block, lds_bytes, ctx->stream, K);
+        else hipLaunchKernelGGL(k_hbm_multi, grid, block, lds_bytes, ctx->stream, K);
+    };
+    if (K.n_tris > 0)  // EXTENSION: scenes with triangle meshes use the BVH-enabled instantiation
+        launch(srt::pathtrace_kernel<3, true, true, false>, srt::pathtrace_kernel<3, true, true, true>,
+               srt::pathtrace_kernel<3, true, false, false>, srt::pathtrace_kernel<3, true, false, true>);
+    else if (use == 1 && in_lds && !multi)
         hipLaunchKernelGGL((srt::pathtrace_kernel<5, false>), grid, block, lds_bytes, ctx->stream, K);
-    else if (use == 3)
+    else if (use == 3 && in_lds && !multi)
         hipLaunchKernelGGL((srt::pathtrace_kernel<3, false>), grid, block, lds_bytes, ctx->stream, K);
     else
-        hipLaunchKernelGGL((srt::pathtrace_kernel<4, false>), grid, block, lds_bytes, ctx->stream, K);
+        launch(srt::pathtrace_kernel<4, false, true, false>, srt::pathtrace_kernel<4, false, true, true>,
+               srt::pathtrace_kernel<4, false, false, false>, srt::pathtrace_kernel<4, false, false, true>);
     SRT_HIP(ctx, hipGetLastError());
     SRT_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
     ctx->launched = true;

@@ -75,6 +75,7 @@ struct KernelParams {
     float mesh_half[3];  // root box half extents
     float mesh_r1;       // their sum + |centre|_1
     int32_t mesh_defer;  // path pool: fewest rays that start a mesh phase (closest_hit)
+    int32_t tile_h;      // rows of a wave's pixel tile: 8, 4, 2 or 1 (pathtrace_kernel)
     float4* accumulator;
     uint32_t* framebuffer;
     unsigned long long* ray_counter;
@@ -688,7 +689,10 @@ __device__ __forceinline__ Lds make_lds(const KernelParams& P, float4* lds, int 
                reinterpret_cast<unsigned*>(wg + waves * WAVE_SCRATCH_BYTES + wave * MESH_WAVE_BYTES)};
 }
 
-template <int MIN_WAVES, bool MESH, bool SCENE_LDS = true>
+// MULTI: the path pool may hand several samples of one pixel out at once (used with small tiles, where
+// there are fewer pixels than lanes).  A separate instantiation because the extra live values cost the
+// full-tile kernel, which sits exactly at its 128-VGPR budget, four spilled registers and 3 % of its speed.
+template <int MIN_WAVES, bool MESH, bool SCENE_LDS = true, bool MULTI = false>
 __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const KernelParams P) {
     extern __shared__ float4 lds_scene[];
     if constexpr (SCENE_LDS) {  // stage the scene image into LDS (coalesced 16-byte loads)
@@ -699,10 +703,14 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
 
     // ---- pixel of this lane ----------------------------------------------------------
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // a wave's tile is TILE_W x P.tile_h pixels (tile_h = 8, or less when the launch would otherwise have
+    // too few workgroups to fill the chip: narrow row bands at high sample counts).  Lanes without a pixel
+    // still work in the path pool.
+    const int tile_h = P.tile_h;
     const int tx = blockIdx.x * WG_W + (wave % WG_TILES_X) * TILE_W + (lane & (TILE_W - 1));
-    const int ty = blockIdx.y * WG_H + (wave / WG_TILES_X) * TILE_H + (lane / TILE_W);
+    const int ty = blockIdx.y * (tile_h * WG_TILES_Y) + (wave / WG_TILES_X) * tile_h + (lane / TILE_W);
     const int W = P.width, H = P.height;
-    const bool in_range = tx < W && ty < P.rows;
+    const bool in_range = tx < W && ty < P.rows && (lane / TILE_W) < tile_h;
     const int x = in_range ? tx : 0, y = in_range ? (P.y0 + ty) : P.y0;
     const uint32_t pixel = (uint32_t)(x + y * W);
 
@@ -844,8 +852,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
 
         // path state of the task this lane is running
         bool busy = false;
-        int slot = 0;
-        uint32_t sidx = 0;
+        uint32_t task = 0;  // sample << 6 | slot (one register: the kernel sits right at its VGPR budget)
         RGB L{0, 0, 0}, T{0, 0, 0};
         V3 sray = v3(0, 0, 1), hn = v3(0, 0, 0), hp = v3(0, 0, 0);
         int hprim = 0, bounce = 0;
@@ -875,14 +882,19 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             }
             if (__builtin_amdgcn_ballot_w64(own_done < count) == 0ull) break;  // every slot finished
 
-            // ---- hand out tasks: the i-th free lane takes the next sample of the i-th slot
-            // that has ring capacity (ballot ranks on both sides, matched through S.work)
+            // ---- hand out tasks: the i-th free lane takes the next sample of the i-th slot that has ring
+            // capacity (ballot ranks on both sides, matched through S.work).  MULTI: when there are more
+            // free lanes than such slots, the lanes are dealt round-robin to the slots and a slot hands out
+            // as many consecutive samples as it is dealt lanes, up to its capacity — so a small tile
+            // (P.tile_h) still keeps all 64 lanes busy
             for (int pass = 0; pass < 2; ++pass) {
                 const unsigned long long freem = __builtin_amdgcn_ballot_w64(!busy);
-                const bool can = own_next < count && own_next < own_done + (uint32_t)depth;
+                const uint32_t lim = count < own_done + (uint32_t)depth ? count : own_done + (uint32_t)depth;
+                const int avail = own_next < lim ? (int)(lim - own_next) : 0;
+                const bool can = avail > 0;
                 const unsigned long long canm = __builtin_amdgcn_ballot_w64(can);
                 if (freem == 0ull || canm == 0ull) break;
-                const int nfree = __builtin_popcountll(freem);
+                const int nfree = __builtin_popcountll(freem), ncan = __builtin_popcountll(canm);
                 // slot priority rotates every round so that all slots advance at the same pace
                 // (a fixed order would starve the high slots and leave them for a thin tail)
                 rot = (rot + 23) & 63;
@@ -890,17 +902,33 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 const int lr = (lane - rot) & 63;
                 const int crank = __builtin_popcountll(canr & ((1ull << lr) - 1ull));
                 const int frank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(freem >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)freem, 0u));
-                unsigned* match = reinterpret_cast<unsigned*>(S.work);  // [64] of (sample << 6 | slot)
-                if (can && crank < nfree) {
-                    match[crank] = (own_next << 6) | (unsigned)lane;
-                    ++own_next;
+                unsigned* match = reinterpret_cast<unsigned*>(S.work);  // [64] of (sample << 6 | slot), ~0 = nothing
+                unsigned m = 0xFFFFFFFFu;
+                if (!MULTI || ncan >= nfree) {  // one sample from each of the first nfree slots
+                    if (can && crank < nfree) {
+                        match[crank] = (own_next << 6) | (unsigned)lane;
+                        ++own_next;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (!busy && frank < ncan) m = match[frank];
+                } else {  // more free lanes than slots: slots hand out several samples, entries may stay empty
+                    if (!busy) match[frank] = 0xFFFFFFFFu;
+                    __builtin_amdgcn_wave_barrier();
+                    if (can) {
+                        int given = 0;
+                        for (int j = crank; j < nfree && given < avail; j += ncan) {
+                            match[j] = ((own_next + (uint32_t)given) << 6) | (unsigned)lane;
+                            ++given;
+                        }
+                        own_next += (uint32_t)given;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (!busy) m = match[frank];
                 }
-                __builtin_amdgcn_wave_barrier();
-                if (!busy && frank < __builtin_popcountll(canm)) {
-                    const unsigned m = match[frank];
-                    sidx = m >> 6;
-                    slot = (int)(m & 63u);
-                    const float* r = rec + slot * 12;
+                if (m != 0xFFFFFFFFu) {
+                    task = m;
+                    const uint32_t sidx = m >> 6;
+                    const float* r = rec + (int)(m & 63u) * 12;
                     const int prim0 = __float_as_int(r[9]);
                     // Raytracer.cpp:162-166 for sample sidx of that pixel
                     rng = srt_rng_key(P.seed, __float_as_uint(r[10]), P.first_sample + sidx);
@@ -974,7 +1002,8 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                     end_path = bounce >= B;
                 }
                 if (end_path) {  // hand the sample colour to the slot's owner
-                    ring[(sidx % (uint32_t)depth) * n_hit + slot] = make_float4(L.r, L.g, L.b, __uint_as_float(sidx));
+                    const uint32_t sidx = task >> 6;
+                    ring[(sidx % (uint32_t)depth) * n_hit + (int)(task & 63u)] = make_float4(L.r, L.g, L.b, __uint_as_float(sidx));
                     busy = false;
                 }
             }

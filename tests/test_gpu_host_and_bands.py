@@ -252,3 +252,25 @@ def test_host_renderer_default_ui_loop(srt, oracle):
     idx = r.pick(64, 36)
     assert idx == 64  # the big ball at (0,0,5) is object 64 of Scene1 and fills the centre
     r.close()
+
+
+@pytest.mark.parametrize("name,w,h,spp,tile", [("Scene1", 1920, 300, 16, 4), ("Scene_indirect", 1920, 128, 16, 2), ("Scene3", 208, 77, 24, 1),
+                                               ("Scene1_reflection", 640, 50, 40, 1)])
+def test_small_tiles_at_high_sample_counts(srt, oracle, name, w, h, spp, tile):
+    """With >= 16 samples per pixel and too few rows to fill the chip, srt_render shrinks a wave's pixel
+    tile (8 rows -> 4 / 2 / 1) and uses the kernel instantiation whose path pool hands several samples
+    of one pixel out at once (narrow stripes of a multi-GPU frame).  `tile` is what the rule picks for
+    these sizes on 256 CUs; whatever it picks, the bits must equal the oracle's — also when resuming."""
+    pt, objs, n = _pt(srt, name, w, h)
+    pt.render(spp=spp, bounces=6, seed=2, count_rays=True)
+    ofb, oacc, orays = _oracle_frame(oracle, objs, n, w, h, spp=spp, bounces=6, seed=2)
+    assert pt.stats().rays == orays
+    assert np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32))
+    assert np.array_equal(pt.framebuffer(), ofb)
+    # resume with another high-count launch on a ragged band
+    pt.render(spp=17, bounces=6, seed=2, first_sample=spp + 1, reset=False, rows=(3, h - 5))
+    ofb2, oacc2, _ = _oracle_frame(oracle, objs, n, w, h, spp=17, bounces=6, seed=2, first_sample=spp + 1, reset=False, accumulator=oacc,
+                                   rows=(3, h - 5))
+    assert np.array_equal(pt.accumulator().view(np.uint32), oacc2.view(np.uint32))
+    assert np.array_equal(pt.framebuffer(rows=(3, h - 5)), ofb2[3:h - 5])
+    pt.close()
