@@ -166,7 +166,7 @@ def main():
         # refine with MEASURED kernel times (untimed set-up, like building an acceleration structure):
         # each band's row costs are rescaled so that the band's total matches its measured time, then
         # the rows are re-partitioned.  A few rounds converge; every rank computes the same split.
-        cal_spp = max(2, spp // 8)
+        cal_spp = spp  # the real launch: the library picks tiling / sample chunking from rows and spp
         best_bands, best_max = bands, float("inf")
         for _ in range(5):
             a, b = bands[rank]

@@ -62,6 +62,12 @@ struct srt_context {
     float4* d_bvh_tris = nullptr;
     int32_t* d_bvh_gidpos = nullptr;
 
+    // sample-chunked launches (narrow row bands at high sample counts): sample colours + per-tile masks
+    float4* d_samples = nullptr;
+    size_t samples_capacity = 0;  // bytes
+    unsigned long long* d_tile_masks = nullptr;
+    size_t tile_masks_capacity = 0;  // entries
+
     srt_environment env;
     HostCamera camera;
     srt_stats stats{};
@@ -200,6 +206,8 @@ int srt_destroy(srt_context* ctx) {
     if (ctx->d_bvh_tris) (void)hipFree(ctx->d_bvh_tris);
     if (ctx->d_bvh_gidpos) (void)hipFree(ctx->d_bvh_gidpos);
     if (ctx->d_pick) (void)hipFree(ctx->d_pick);
+    if (ctx->d_samples) (void)hipFree(ctx->d_samples);
+    if (ctx->d_tile_masks) (void)hipFree(ctx->d_tile_masks);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -471,29 +479,87 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     const long long want = 15LL * ctx->cu_count;  // ~4 rounds of the 4 workgroups a CU holds; measured on bands of 30..400 rows
     while (tile_h > 1 && p->sample_count >= 16 && wg_x * ((K.rows + tile_h * srt::WG_TILES_Y - 1) / (tile_h * srt::WG_TILES_Y)) < want) tile_h >>= 1;
     if (tile_env == 8 || tile_env == 4 || tile_env == 2 || tile_env == 1) tile_h = tile_env;
+    // Sample-chunked launch, for 64 samples per pixel and more: keep the full 8x8 tiles but give every tile
+    // to several workgroups, each tracing one chunk (>= 16) of the samples and storing the colours; a
+    // second, streaming kernel folds them in order (the running mean is order-dependent).  A narrow stripe
+    // of a multi-GPU frame then runs like the full single-GPU frame — many short workgroups — instead of
+    // few long ones whose tail idles the chip: 135 rows x 256 spp 4.9 ms -> 2.2 ms, and still ~10 % on a
+    // full 1080p frame at 256 spp.  Costs 1 KiB of HBM per tile and sample (falls back to small tiles
+    // when that is not available).
+    static const int defer_env = [] {
+        const char* v = getenv("SRT_DEFER");
+        return v ? atoi(v) : -1;  // 0: never, n > 0: force n samples per chunk
+    }();
+    const long long wg_y8 = (K.rows + srt::WG_H - 1) / srt::WG_H, wg8 = wg_x * wg_y8;
+    int chunk = 0, chunks = 1;
+    if (tile_env == 0 && defer_env != 0 && (p->sample_count >= 64 || defer_env > 0) && p->sample_count >= 32) {
+        long long c = (96LL * ctx->cu_count + wg8 - 1) / wg8;  // about 24 k workgroups in flight over the launch
+        if (c > p->sample_count / 16) c = p->sample_count / 16;
+        if (c >= 2 || defer_env > 0) {
+            chunk = (int)((p->sample_count + c - 1) / c);
+            if (defer_env > 0) chunk = defer_env;
+            chunks = (int)((p->sample_count + chunk - 1) / chunk);
+        }
+    }
+    if (chunks >= 2) {
+        const size_t tiles = (size_t)wg8 * srt::WG_TILES_X * srt::WG_TILES_Y;
+        const size_t need = tiles * (size_t)p->sample_count * 64 * sizeof(float4);
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        bool ok = need <= ((size_t)24 << 30) && (need <= ctx->samples_capacity || need <= free_b / 4);
+        if (ok && need > ctx->samples_capacity) {
+            if (ctx->d_samples) (void)hipFree(ctx->d_samples);
+            ctx->d_samples = nullptr;
+            ctx->samples_capacity = 0;
+            if (hipMalloc((void**)&ctx->d_samples, need) == hipSuccess) ctx->samples_capacity = need;
+            else ok = false, (void)hipGetLastError();
+        }
+        if (ok && tiles > ctx->tile_masks_capacity) {
+            if (ctx->d_tile_masks) (void)hipFree(ctx->d_tile_masks);
+            ctx->d_tile_masks = nullptr;
+            ctx->tile_masks_capacity = 0;
+            if (hipMalloc((void**)&ctx->d_tile_masks, tiles * sizeof(unsigned long long)) == hipSuccess) ctx->tile_masks_capacity = tiles;
+            else ok = false, (void)hipGetLastError();
+        }
+        if (!ok) chunks = 1, chunk = 0;  // no room for the sample buffer: small tiles instead
+    }
+    const bool defer = chunks >= 2;
+    if (defer) tile_h = srt::TILE_H;
     K.tile_h = tile_h;
-    dim3 grid((unsigned)wg_x, (unsigned)((K.rows + tile_h * srt::WG_TILES_Y - 1) / (tile_h * srt::WG_TILES_Y)));
+    K.chunk = defer ? chunk : 0;
+    K.sample_rows = ctx->d_samples;
+    K.tile_masks = ctx->d_tile_masks;
+    dim3 grid((unsigned)wg_x, (unsigned)((K.rows + tile_h * srt::WG_TILES_Y - 1) / (tile_h * srt::WG_TILES_Y)), (unsigned)chunks);
     dim3 block(srt::WG_THREADS);
     SRT_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
-    // instantiation: mesh or not, scene image in LDS or HBM, small tiles (multi-sample hand-out) or full
-    // ones; variants 1 / 3 are a development aid for in-process A/B timing.  All are bit-identical.
+    // instantiation: mesh or not, scene image in LDS or HBM, full tiles / small tiles (multi-sample
+    // hand-out) / sample chunks; variants 1 / 3 are a development aid for in-process A/B timing.
+    // All are bit-identical.
     const bool in_lds = ctx->scene_in_lds[img], multi = tile_h < srt::TILE_H;
-    auto launch = [&](auto k_lds, auto k_lds_multi, auto k_hbm, auto k_hbm_multi) {
-        if (in_lds && !multi) hipLaunchKernelGGL(k_lds, grid, block, lds_bytes, ctx->stream, K);
-        else if (in_lds) hipLaunchKernelGGL(k_lds_multi, grid, block, lds_bytes, ctx->stream, K);
-        else if (!multi) hipLaunchKernelGGL(k_hbm, grid, block, lds_bytes, ctx->stream, K);
-        else hipLaunchKernelGGL(k_hbm_multi, grid, block, lds_bytes, ctx->stream, K);
+    auto launch = [&](auto k_lds, auto k_lds_multi, auto k_lds_defer, auto k_hbm, auto k_hbm_multi, auto k_hbm_defer) {
+        if (in_lds && defer) hipLaunchKernelGGL(k_lds_defer, grid, block, lds_bytes, ctx->stream, K);
+        else if (in_lds && multi) hipLaunchKernelGGL(k_lds_multi, grid, block, lds_bytes, ctx->stream, K);
+        else if (in_lds) hipLaunchKernelGGL(k_lds, grid, block, lds_bytes, ctx->stream, K);
+        else if (defer) hipLaunchKernelGGL(k_hbm_defer, grid, block, lds_bytes, ctx->stream, K);
+        else if (multi) hipLaunchKernelGGL(k_hbm_multi, grid, block, lds_bytes, ctx->stream, K);
+        else hipLaunchKernelGGL(k_hbm, grid, block, lds_bytes, ctx->stream, K);
     };
     if (K.n_tris > 0)  // EXTENSION: scenes with triangle meshes use the BVH-enabled instantiation
-        launch(srt::pathtrace_kernel<3, true, true, false>, srt::pathtrace_kernel<3, true, true, true>,
-               srt::pathtrace_kernel<3, true, false, false>, srt::pathtrace_kernel<3, true, false, true>);
-    else if (use == 1 && in_lds && !multi)
+        launch(srt::pathtrace_kernel<3, true, true, false, false>, srt::pathtrace_kernel<3, true, true, true, false>,
+               srt::pathtrace_kernel<3, true, true, false, true>, srt::pathtrace_kernel<3, true, false, false, false>,
+               srt::pathtrace_kernel<3, true, false, true, false>, srt::pathtrace_kernel<3, true, false, false, true>);
+    else if (use == 1 && in_lds && !multi && !defer)
         hipLaunchKernelGGL((srt::pathtrace_kernel<5, false>), grid, block, lds_bytes, ctx->stream, K);
-    else if (use == 3 && in_lds && !multi)
+    else if (use == 3 && in_lds && !multi && !defer)
         hipLaunchKernelGGL((srt::pathtrace_kernel<3, false>), grid, block, lds_bytes, ctx->stream, K);
     else
-        launch(srt::pathtrace_kernel<4, false, true, false>, srt::pathtrace_kernel<4, false, true, true>,
-               srt::pathtrace_kernel<4, false, false, false>, srt::pathtrace_kernel<4, false, false, true>);
+        launch(srt::pathtrace_kernel<4, false, true, false, false>, srt::pathtrace_kernel<4, false, true, true, false>,
+               srt::pathtrace_kernel<4, false, true, false, true>, srt::pathtrace_kernel<4, false, false, false, false>,
+               srt::pathtrace_kernel<4, false, false, true, false>, srt::pathtrace_kernel<4, false, false, false, true>);
+    if (defer) {
+        SRT_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(srt::fold_kernel, dim3((unsigned)wg8), dim3(256), 0, ctx->stream, K, (int)wg_x);
+    }
     SRT_HIP(ctx, hipGetLastError());
     SRT_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
     ctx->launched = true;

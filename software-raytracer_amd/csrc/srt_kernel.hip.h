@@ -76,6 +76,11 @@ struct KernelParams {
     float mesh_r1;       // their sum + |centre|_1
     int32_t mesh_defer;  // path pool: fewest rays that start a mesh phase (closest_hit)
     int32_t tile_h;      // rows of a wave's pixel tile: 8, 4, 2 or 1 (pathtrace_kernel)
+    // sample-chunked launches (DEFER instantiation): workgroup z traces samples [z*chunk, (z+1)*chunk) of
+    // its tiles and stores the colours in sample order; fold_kernel then folds them into the running mean
+    int32_t chunk;           // samples per workgroup, 0 = everything in one workgroup (no sample buffer)
+    float4* sample_rows;     // [tile][sample][64 slots] sample colours
+    unsigned long long* tile_masks;  // [tile] which pixels of the tile are traced (slot k = k-th set bit)
     float4* accumulator;
     uint32_t* framebuffer;
     unsigned long long* ray_counter;
@@ -669,6 +674,36 @@ __device__ __forceinline__ uint32_t pack_channel(float v) {  // Common.hpp:190-2
     return (uint32_t)(uint8_t)s;
 }
 
+// SetScreenPixel accumulate half (Raytracer.cpp:65-71) for sample index sidx (0-based in
+// this launch); the colour's alpha is always +0
+__device__ __forceinline__ void accumulate_sample(const KernelParams& P, float4& acc, RGB c, uint32_t sidx) {
+    const uint32_t frame = P.first_sample + sidx;
+    if (sidx == 0 && (P.flags & 1u) != 0) {
+        acc = make_float4(c.r, c.g, c.b, 0.0f);
+    } else {
+        // :66  float weight = 1.0 / ACCUMULATIONFRAMES (double divide, rounded once).  For
+        // frame <= 2^24 the float divide gives the same bits (1/f cannot sit within 2^-53
+        // of a binary32 rounding boundary unless it is exact; checked exhaustively in tests).
+        float weight = frame <= 16777216u ? 1.0f / (float)(int)frame : (float)(1.0 / (double)(int)frame);
+        float om = 1 - weight;
+        acc.x = clamp0(clamp0(acc.x * om) + clamp0(c.r * weight));  // :67
+        acc.y = clamp0(clamp0(acc.y * om) + clamp0(c.g * weight));
+        acc.z = clamp0(clamp0(acc.z * om) + clamp0(c.b * weight));
+        acc.w = clamp0(clamp0(acc.w * om) + clamp0(0.0f * weight));
+    }
+}
+// SetScreenPixel tone-map + pack + the two stores (Raytracer.cpp:64,73-75)
+__device__ __forceinline__ void store_pixel(const KernelParams& P, uint32_t pix, const float4 acc) {
+    P.accumulator[pix] = acc;
+    float r = clamp0(acc.x / clamp0(1.0f + acc.x));
+    float g = clamp0(acc.y / clamp0(1.0f + acc.y));
+    float b = clamp0(acc.z / clamp0(1.0f + acc.z));
+    float a = clamp0(acc.w / clamp0(0.0f + acc.w));
+    uint32_t px = pack_channel(a) << 24 | pack_channel(r) << 16 | pack_channel(g) << 8 | pack_channel(b);
+    const uint32_t py = pix / (uint32_t)P.width, pxx = pix - py * (uint32_t)P.width;
+    P.framebuffer[(size_t)(P.height - 1 - (int)py) * P.width + pxx] = px;
+}
+
 // Per-wave view of the workgroup's LDS: [scene image (SCENE_LDS only)] [waves x WAVE_SCRATCH_BYTES]
 // [waves x MESH_WAVE_BYTES (mesh kernel only)].  SCENE_LDS == false is the fallback for scene images
 // that do not fit next to the scratch (thousands of analytic primitives): the same image is then read
@@ -692,7 +727,11 @@ __device__ __forceinline__ Lds make_lds(const KernelParams& P, float4* lds, int 
 // MULTI: the path pool may hand several samples of one pixel out at once (used with small tiles, where
 // there are fewer pixels than lanes).  A separate instantiation because the extra live values cost the
 // full-tile kernel, which sits exactly at its 128-VGPR budget, four spilled registers and 3 % of its speed.
-template <int MIN_WAVES, bool MESH, bool SCENE_LDS = true, bool MULTI = false>
+// DEFER: sample-chunked launch (P.chunk > 0, grid z = chunk index) for narrow row bands at high sample
+// counts, where one workgroup per tile for ALL samples would leave too few, too long workgroups.  The
+// running mean is order-dependent (Raytracer.cpp:67), so chunks cannot fold on their own: the owner lanes
+// store the colours, in sample order, as coalesced rows of P.sample_rows and fold_kernel does the fold.
+template <int MIN_WAVES, bool MESH, bool SCENE_LDS = true, bool MULTI = false, bool DEFER = false>
 __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const KernelParams P) {
     extern __shared__ float4 lds_scene[];
     if constexpr (SCENE_LDS) {  // stage the scene image into LDS (coalesced 16-byte loads)
@@ -737,46 +776,21 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     const Hit h0 = closest_hit<MESH>(S, P, cam, dir0, true, 1, parked);
 
     const bool reset = (P.flags & 1u) != 0;
-    const uint32_t count = P.sample_count;
+    // samples of this workgroup: all of them, or chunk blockIdx.z of the launch
+    const uint32_t s_base = DEFER ? blockIdx.z * (uint32_t)P.chunk : 0u;
+    const uint32_t count = DEFER ? (P.sample_count - s_base < (uint32_t)P.chunk ? P.sample_count - s_base : (uint32_t)P.chunk) : P.sample_count;
     const int B = P.max_bounces;
     unsigned rays = 0;
 
-    // SetScreenPixel accumulate half (Raytracer.cpp:65-71) for sample index sidx (0-based in
-    // this launch); the colour's alpha is always +0
-    auto accumulate = [&](float4& acc, RGB c, uint32_t sidx) {
-        const uint32_t frame = P.first_sample + sidx;
-        if (sidx == 0 && reset) {
-            acc = make_float4(c.r, c.g, c.b, 0.0f);
-        } else {
-            // :66  float weight = 1.0 / ACCUMULATIONFRAMES (double divide, rounded once).  For
-            // frame <= 2^24 the float divide gives the same bits (1/f cannot sit within 2^-53
-            // of a binary32 rounding boundary unless it is exact; checked exhaustively in tests).
-            float weight = frame <= 16777216u ? 1.0f / (float)(int)frame : (float)(1.0 / (double)(int)frame);
-            float om = 1 - weight;
-            acc.x = clamp0(clamp0(acc.x * om) + clamp0(c.r * weight));  // :67
-            acc.y = clamp0(clamp0(acc.y * om) + clamp0(c.g * weight));
-            acc.z = clamp0(clamp0(acc.z * om) + clamp0(c.b * weight));
-            acc.w = clamp0(clamp0(acc.w * om) + clamp0(0.0f * weight));
-        }
-    };
-    // SetScreenPixel tone-map + pack + the two stores (Raytracer.cpp:64,73-75)
-    auto write_pixel = [&](uint32_t pix, const float4 acc) {
-        P.accumulator[pix] = acc;
-        float r = clamp0(acc.x / clamp0(1.0f + acc.x));
-        float g = clamp0(acc.y / clamp0(1.0f + acc.y));
-        float b = clamp0(acc.z / clamp0(1.0f + acc.z));
-        float a = clamp0(acc.w / clamp0(0.0f + acc.w));
-        uint32_t px = pack_channel(a) << 24 | pack_channel(r) << 16 | pack_channel(g) << 8 | pack_channel(b);
-        const uint32_t py = pix / (uint32_t)W, pxx = pix - py * (uint32_t)W;
-        P.framebuffer[(size_t)(H - 1 - (int)py) * W + pxx] = px;
-    };
+    auto accumulate = [&](float4& acc, RGB c, uint32_t sidx) { accumulate_sample(P, acc, c, sidx); };
+    auto write_pixel = [&](uint32_t pix, const float4 acc) { store_pixel(P, pix, acc); };
 
     // ---- pixels whose colour does not depend on the sample: finish them right here --------
     //  primary miss -> env(dir0) every frame (:143-145); MAXBOUNCES == 0 -> EmissiveColor (:162,212)
     //  SIMPLEDRAW -> the one-ray preview shader (:147-160), no random draws
     const bool preview = (P.flags & 4u) != 0;
     const bool traced = in_range && h0.prim >= 0 && B > 0 && !preview;
-    if (in_range && !traced) {
+    if (in_range && !traced && (!DEFER || blockIdx.z == 0)) {  // (chunked: once, by the first chunk, for all samples)
         RGB c;
         if (h0.prim < 0) {
             c = environment(P, dir0);
@@ -810,8 +824,8 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             c = RGB{clamp0(m1.y), clamp0(m1.z), clamp0(m1.w)};
         }
         float4 acc = reset ? make_float4(0, 0, 0, 0) : P.accumulator[pixel];
-        for (uint32_t i = 0; i < count; ++i) accumulate(acc, c, i);
-        rays += count;
+        for (uint32_t i = 0; i < P.sample_count; ++i) accumulate(acc, c, i);
+        rays += P.sample_count;
         write_pixel(pixel, acc);
     }
 
@@ -823,6 +837,8 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     // and folds the ring into the running mean strictly in sample order (the mean is
     // order-dependent, Raytracer.cpp:67), then stores the pixel at the end.
     const unsigned long long hitmask = __builtin_amdgcn_ballot_w64(traced);
+    const size_t tile_id = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (WG_TILES_X * WG_TILES_Y) + wave;
+    if (DEFER && blockIdx.z == 0 && lane == 0) P.tile_masks[tile_id] = hitmask;
     const int n_hit = __builtin_popcountll(hitmask);
     if (n_hit > 0) {
         float* rec = S.pix;  // [64][12]: dir0, n0, p0, prim0, rng pixel (block anchor), output pixel
@@ -847,7 +863,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         float4 acc = make_float4(0, 0, 0, 0);
         if (owner) {
             own_pixel = __float_as_uint(rec[lane * 12 + 11]);
-            if (!reset) acc = P.accumulator[own_pixel];
+            if (!DEFER && !reset) acc = P.accumulator[own_pixel];
         }
 
         // path state of the task this lane is running
@@ -876,7 +892,10 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 }
                 if (__builtin_amdgcn_ballot_w64(ready) == 0ull) break;
                 if (ready) {
-                    accumulate(acc, RGB{e.x, e.y, e.z}, own_done);
+                    if constexpr (DEFER)  // row (tile, sample) of the sample buffer: 64 slots of 16 B, coalesced
+                        P.sample_rows[(tile_id * P.sample_count + s_base + own_done) * 64 + lane] = e;
+                    else
+                        accumulate(acc, RGB{e.x, e.y, e.z}, own_done);
                     ++own_done;
                 }
             }
@@ -931,7 +950,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                     const float* r = rec + (int)(m & 63u) * 12;
                     const int prim0 = __float_as_int(r[9]);
                     // Raytracer.cpp:162-166 for sample sidx of that pixel
-                    rng = srt_rng_key(P.seed, __float_as_uint(r[10]), P.first_sample + sidx);
+                    rng = srt_rng_key(P.seed, __float_as_uint(r[10]), P.first_sample + s_base + sidx);
                     uint32_t rr = srt_mix32(rng) >> 17;
                     rng += 0x9E3779B9U;
                     float4 m0 = S.mat(prim0, 0), m1 = S.mat(prim0, 1);
@@ -1009,7 +1028,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (owner) write_pixel(own_pixel, acc);
+        if (!DEFER && owner) write_pixel(own_pixel, acc);
     }
 
     if (P.flags & 2u) {  // SRT_RENDER_COUNT_RAYS
@@ -1017,6 +1036,42 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
         if (lane == 0 && tot) atomicAdd(P.ray_counter, tot);
     }
+}
+
+// Second half of a sample-chunked launch: one wave per tile, lane k folds slot k's colours, in sample
+// order, into the running mean and stores the pixel — the very operations the owner lanes of
+// pathtrace_kernel perform when a workgroup traces all samples itself.  Streams the sample buffer once.
+__global__ void __launch_bounds__(256) fold_kernel(const KernelParams P, int tiles_x_wg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t wg = blockIdx.x;
+    const size_t tile_id = wg * (WG_TILES_X * WG_TILES_Y) + wave;
+    const unsigned long long mask = P.tile_masks[tile_id];
+    const int n_hit = __builtin_popcountll(mask);
+    if (lane >= n_hit) return;
+    // the lane-th set bit of the mask is this slot's lane (pixel) in the tile
+    unsigned long long m = mask;
+    for (int i = 0; i < lane; ++i) m &= m - 1ull;
+    const int bit = __builtin_ctzll(m);
+    const int bx = (int)(wg % (size_t)tiles_x_wg), by = (int)(wg / (size_t)tiles_x_wg);
+    const int x = bx * WG_W + (wave % WG_TILES_X) * TILE_W + (bit & (TILE_W - 1));
+    const int y = P.y0 + by * WG_H + (wave / WG_TILES_X) * TILE_H + (bit / TILE_W);
+    const uint32_t pixel = (uint32_t)(x + y * P.width);
+    float4 acc = (P.flags & 1u) ? make_float4(0, 0, 0, 0) : P.accumulator[pixel];
+    const float4* row = P.sample_rows + tile_id * P.sample_count * 64 + lane;
+    const uint32_t n = P.sample_count;
+    uint32_t s = 0;
+    for (; s + 8 <= n; s += 8) {  // eight loads in flight per lane
+        float4 c[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c[k] = row[(size_t)(s + k) * 64];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) accumulate_sample(P, acc, RGB{c[k].x, c[k].y, c[k].z}, s + k);
+    }
+    for (; s < n; ++s) {
+        const float4 c = row[(size_t)s * 64];
+        accumulate_sample(P, acc, RGB{c.x, c.y, c.z}, s);
+    }
+    store_pixel(P, pixel, acc);
 }
 
 // Picking (Raytracer.cpp:525-541): one wave, every lane traces the same ray.

@@ -255,12 +255,15 @@ def test_host_renderer_default_ui_loop(srt, oracle):
 
 
 @pytest.mark.parametrize("name,w,h,spp,tile", [("Scene1", 1920, 300, 16, 4), ("Scene_indirect", 1920, 128, 16, 2), ("Scene3", 208, 77, 24, 1),
-                                               ("Scene1_reflection", 640, 50, 40, 1)])
-def test_small_tiles_at_high_sample_counts(srt, oracle, name, w, h, spp, tile):
+                                               ("Scene1_reflection", 640, 50, 40, 1), ("Scene1", 320, 64, 64, 0), ("Scene_indirect", 200, 41, 80, 0),
+                                               ("Scene2", 1000, 30, 100, 0)])
+def test_small_tiles_and_sample_chunks_at_high_sample_counts(srt, oracle, name, w, h, spp, tile):
     """With >= 16 samples per pixel and too few rows to fill the chip, srt_render shrinks a wave's pixel
     tile (8 rows -> 4 / 2 / 1) and uses the kernel instantiation whose path pool hands several samples
-    of one pixel out at once (narrow stripes of a multi-GPU frame).  `tile` is what the rule picks for
-    these sizes on 256 CUs; whatever it picks, the bits must equal the oracle's — also when resuming."""
+    of one pixel out at once; from 64 samples per pixel it splits the samples of a tile over several
+    workgroups and folds the stored colours in a second kernel (narrow stripes of a multi-GPU frame).
+    `tile` is what the rule picks for these sizes on 256 CUs (0 = sample chunks); whatever it picks, the
+    bits must equal the oracle's — also when resuming on a ragged band."""
     pt, objs, n = _pt(srt, name, w, h)
     pt.render(spp=spp, bounces=6, seed=2, count_rays=True)
     ofb, oacc, orays = _oracle_frame(oracle, objs, n, w, h, spp=spp, bounces=6, seed=2)
@@ -268,9 +271,22 @@ def test_small_tiles_at_high_sample_counts(srt, oracle, name, w, h, spp, tile):
     assert np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32))
     assert np.array_equal(pt.framebuffer(), ofb)
     # resume with another high-count launch on a ragged band
-    pt.render(spp=17, bounces=6, seed=2, first_sample=spp + 1, reset=False, rows=(3, h - 5))
-    ofb2, oacc2, _ = _oracle_frame(oracle, objs, n, w, h, spp=17, bounces=6, seed=2, first_sample=spp + 1, reset=False, accumulator=oacc,
+    more = 17 if spp < 64 else 70
+    pt.render(spp=more, bounces=6, seed=2, first_sample=spp + 1, reset=False, rows=(3, h - 5))
+    ofb2, oacc2, _ = _oracle_frame(oracle, objs, n, w, h, spp=more, bounces=6, seed=2, first_sample=spp + 1, reset=False, accumulator=oacc,
                                    rows=(3, h - 5))
     assert np.array_equal(pt.accumulator().view(np.uint32), oacc2.view(np.uint32))
     assert np.array_equal(pt.framebuffer(rows=(3, h - 5)), ofb2[3:h - 5])
+    pt.close()
+
+
+def test_progressive_blocks_with_sample_chunks(srt, oracle):
+    """steps x steps blocks (Raytracer.cpp:233-248) together with a sample-chunked launch (>= 64 spp)."""
+    w, h = 150, 84
+    pt, objs, n = _pt(srt, "Scene3", w, h)
+    kw = dict(spp=72, bounces=4, seed=9, steps=2, stripe_width=w // 16 + 1)
+    pt.render(**kw)
+    ofb, oacc, _ = _oracle_frame(oracle, objs, n, w, h, **kw)
+    assert np.array_equal(pt.framebuffer(), ofb)
+    assert np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32))
     pt.close()

@@ -34,9 +34,10 @@ def _render_both(srt, oracle, objs, meshes, w, h, **kw):
     return pt, (fb, acc, st.rays), (ofb, oacc, orays), keep
 
 
-# the last two cases have >= 16 spp on a small frame: 1-row tiles and the multi-sample hand-out of the mesh kernel
+# the last three cases have >= 16 spp on a small frame: 1-row tiles and the multi-sample hand-out of the mesh
+# kernel; >= 64 spp: sample chunks + fold kernel
 @pytest.mark.parametrize("stacks,slices,w,h,spp,bounces", [(8, 12, 160, 90, 2, 4), (24, 32, 128, 72, 2, 8), (48, 64, 96, 54, 1, 8),
-                                                           (16, 24, 96, 54, 20, 6), (32, 32, 480, 40, 16, 8)])
+                                                           (16, 24, 96, 54, 20, 6), (32, 32, 480, 40, 16, 8), (16, 16, 120, 50, 70, 5)])
 def test_mesh_scene_bit_exact_vs_bruteforce_oracle(srt, oracle, stacks, slices, w, h, spp, bounces):
     objs, meshes = _scene1_with_mesh(oracle, stacks, slices)
     pt, g, o, keep = _render_both(srt, oracle, objs, meshes, w, h, spp=spp, bounces=bounces, seed=1)
