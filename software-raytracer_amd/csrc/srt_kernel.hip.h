@@ -27,6 +27,10 @@
 //       - EXTENSION, triangle meshes: wave-cooperative traversal of an 8-wide quantized BVH (LDS
 //         LIFO of (ray, node) items, 8 lanes per item when few wait), srt_mesh_bvh.h.
 //   * counter-based RNG keyed (seed, absolute pixel, sample, draw#): include/srt_defs.h.
+//   * launches with few rows and many samples per pixel (a stripe of a multi-GPU frame) would have too few,
+//     too long workgroups: from 16 spp the tile of a wave shrinks (P.tile_h rows, MULTI hand-out), from 64
+//     spp the samples of a tile are split over several workgroups (DEFER) that store the colours as rows of
+//     a sample buffer, and fold_kernel folds them in sample order (HBM-bound, 16 B per traced sample).
 //
 // Bit-exactness rules (the file is compiled with -ffp-contract=off; hipcc's default
 // correctly-rounded fp32 divide/sqrt stays on; fp32 denormals are not flushed):
