@@ -504,9 +504,11 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     if (chunks >= 2) {
         const size_t tiles = (size_t)wg8 * srt::WG_TILES_X * srt::WG_TILES_Y;
         const size_t need = tiles * (size_t)p->sample_count * 64 * sizeof(float4);
-        size_t free_b = 0, total_b = 0;
-        (void)hipMemGetInfo(&free_b, &total_b);
-        bool ok = need <= ((size_t)24 << 30) && (need <= ctx->samples_capacity || need <= free_b / 4);
+        bool ok = need <= ((size_t)24 << 30);
+        if (ok && need > ctx->samples_capacity) {  // growing: take at most a quarter of what is free
+            size_t free_b = 0, total_b = 0;
+            ok = hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= (free_b + ctx->samples_capacity) / 4;
+        }
         if (ok && need > ctx->samples_capacity) {
             if (ctx->d_samples) (void)hipFree(ctx->d_samples);
             ctx->d_samples = nullptr;
