@@ -492,7 +492,8 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     }();
     const long long wg_y8 = (K.rows + srt::WG_H - 1) / srt::WG_H, wg8 = wg_x * wg_y8;
     int chunk = 0, chunks = 1;
-    if (tile_env == 0 && defer_env != 0 && (p->sample_count >= 64 || defer_env > 0) && p->sample_count >= 32) {
+    // (scenes with meshes from 32 spp: their few, heavy tiles profit earlier — config 4 at 32 spp +20 %)
+    if (tile_env == 0 && defer_env != 0 && (p->sample_count >= 64 || defer_env > 0 || K.n_tris > 0) && p->sample_count >= 32) {
         long long c = (96LL * ctx->cu_count + wg8 - 1) / wg8;  // about 24 k workgroups in flight over the launch
         if (c > p->sample_count / 16) c = p->sample_count / 16;
         if (c >= 2 || defer_env > 0) {
