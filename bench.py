@@ -168,7 +168,7 @@ def main():
         # the rows are re-partitioned.  A few rounds converge; every rank computes the same split.
         cal_spp = spp  # the real launch: the library picks tiling / sample chunking from rows and spp
         best_bands, best_max = bands, float("inf")
-        for _ in range(5):
+        for _ in range(8):
             a, b = bands[rank]
             pt.render(spp=cal_spp, bounces=args.bounces, seed=SEED, first_sample=1, reset=True, rows=(a, b))
             t_loc = torch.tensor([pt.stats().kernel_ms], dtype=torch.float64, device=cdev)
@@ -177,7 +177,7 @@ def main():
             times = [float(t.item()) for t in t_all]
             if max(times) < best_max:  # keep the best MEASURED split (identical decision on every rank)
                 best_bands, best_max = bands, max(times)
-            if max(times) <= 1.03 * (sum(times) / world):
+            if max(times) <= 1.02 * (sum(times) / world):
                 break
             for k, (x, y) in enumerate(bands):
                 tot = sum(row_cost[x:y]) or 1.0
