@@ -28,7 +28,7 @@ for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
         if "pathtrace_kernel" in row["Kernel_Name"]:
             vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
 summ = {k: {"dispatches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)} for k, v in sorted(vals.items())}
-doc = {"round": int(rnd.strip("r")), "kernel": "srt::pathtrace_kernel<4,false,true>", "workload": "Scene1 1920x1080 spp32 b8",
+doc = {"round": int(rnd.strip("r")), "kernel": "srt::pathtrace_kernel<4,false,true,false,false>", "workload": "Scene1 1920x1080 spp32 b8",
        "commands": ["rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline",
                     "rocprofv3 --pmc <one group per pass> --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"],
        "counters_per_dispatch": summ}
