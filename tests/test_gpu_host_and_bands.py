@@ -290,3 +290,30 @@ def test_progressive_blocks_with_sample_chunks(srt, oracle):
     assert np.array_equal(pt.framebuffer(), ofb)
     assert np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32))
     pt.close()
+
+
+def test_sample_chunks_extremes(srt, oracle):
+    """Sample-chunked launches at the edges: thousands of samples on a frame smaller than one workgroup
+    (hundreds of chunks per tile), and a band without a single traced pixel (all sky: every tile mask 0)."""
+    w, h = 13, 7
+    pt, objs, n = _pt(srt, "Scene1", w, h)
+    kw = dict(spp=4100, bounces=3, seed=21)
+    pt.render(count_rays=True, **kw)
+    ofb, oacc, orays = _oracle_frame(oracle, objs, n, w, h, **kw)
+    assert pt.stats().rays == orays
+    assert np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32))
+    assert np.array_equal(pt.framebuffer(), ofb)
+    pt.close()
+    # a frame without a single traced pixel: every tile mask is 0, the fold kernel has nothing to do
+    w, h = 320, 180
+    oarr, n = oracle.make_objects([dict(type=oracle.OBJ_SPHERE, position=(0.0, 0.0, -50.0), radius=1.0)])  # behind the camera
+    pt = srt.PathTracer(w, h)
+    pt.set_scene(C.cast(oarr, C.POINTER(srt.Object)), n)
+    pt.set_camera(srt.default_camera())
+    kw = dict(spp=96, bounces=8, seed=1, rows=(10, 150))
+    pt.render(count_rays=True, **kw)
+    ofb, oacc, orays = oracle.render(oarr, n, oracle.default_environment(), oracle.default_camera(), w, h, **kw)
+    assert pt.stats().rays == orays == w * 140 * 96  # one (missing) primary ray per sample
+    assert np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32))
+    assert np.array_equal(pt.framebuffer(rows=(10, 150)), ofb[10:150])
+    pt.close()
