@@ -85,6 +85,10 @@ struct KernelParams {
     int32_t chunk;           // samples per workgroup, 0 = everything in one workgroup (no sample buffer)
     float4* sample_rows;     // [tile][sample][64 slots] sample colours
     unsigned long long* tile_masks;  // [tile] which pixels of the tile are traced (slot k = k-th set bit)
+    // cost-ordered dispatch: workgroup i of the launch works on tile block wg_order[i] (NULL: i); every
+    // wave adds its ray count to wg_cost[block] (NULL: not recorded) for the order of the next launch
+    const uint32_t* wg_order;
+    uint32_t* wg_cost;
     float4* accumulator;
     uint32_t* framebuffer;
     unsigned long long* ray_counter;
@@ -750,8 +754,13 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     // too few workgroups to fill the chip: narrow row bands at high sample counts).  Lanes without a pixel
     // still work in the path pool.
     const int tile_h = P.tile_h;
-    const int tx = blockIdx.x * WG_W + (wave % WG_TILES_X) * TILE_W + (lane & (TILE_W - 1));
-    const int ty = blockIdx.y * (tile_h * WG_TILES_Y) + (wave / WG_TILES_X) * tile_h + (lane / TILE_W);
+    // which block of tiles: the hardware starts workgroups in linear order, wg_order maps that order to
+    // blocks sorted by decreasing cost so that the expensive ones do not end up in the tail
+    uint32_t block_id = blockIdx.y * gridDim.x + blockIdx.x;
+    if (P.wg_order) block_id = P.wg_order[block_id];
+    const int bx = (int)(block_id % gridDim.x), by = (int)(block_id / gridDim.x);
+    const int tx = bx * WG_W + (wave % WG_TILES_X) * TILE_W + (lane & (TILE_W - 1));
+    const int ty = by * (tile_h * WG_TILES_Y) + (wave / WG_TILES_X) * tile_h + (lane / TILE_W);
     const int W = P.width, H = P.height;
     const bool in_range = tx < W && ty < P.rows && (lane / TILE_W) < tile_h;
     const int x = in_range ? tx : 0, y = in_range ? (P.y0 + ty) : P.y0;
@@ -841,7 +850,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     // and folds the ring into the running mean strictly in sample order (the mean is
     // order-dependent, Raytracer.cpp:67), then stores the pixel at the end.
     const unsigned long long hitmask = __builtin_amdgcn_ballot_w64(traced);
-    const size_t tile_id = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (WG_TILES_X * WG_TILES_Y) + wave;
+    const size_t tile_id = (size_t)block_id * (WG_TILES_X * WG_TILES_Y) + wave;
     if (DEFER && blockIdx.z == 0 && lane == 0) P.tile_masks[tile_id] = hitmask;
     const int n_hit = __builtin_popcountll(hitmask);
     if (n_hit > 0) {
@@ -1035,10 +1044,13 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         if (!DEFER && owner) write_pixel(own_pixel, acc);
     }
 
-    if (P.flags & 2u) {  // SRT_RENDER_COUNT_RAYS
+    if ((P.flags & 2u) || P.wg_cost) {  // SRT_RENDER_COUNT_RAYS / cost feedback for the dispatch order
         unsigned long long tot = rays;
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
-        if (lane == 0 && tot) atomicAdd(P.ray_counter, tot);
+        if (lane == 0 && tot) {
+            if (P.flags & 2u) atomicAdd(P.ray_counter, tot);
+            if (P.wg_cost) atomicAdd(&P.wg_cost[block_id], (uint32_t)(tot > 0xFFFFFFFFull ? 0xFFFFFFFFull : tot));
+        }
     }
 }
 
