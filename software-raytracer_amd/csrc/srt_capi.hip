@@ -559,8 +559,8 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     // Cost-ordered dispatch.  The hardware starts workgroups in linear order; with the natural order the
     // last ones to start are whatever lies at the top of the band, and the chip idles while a few expensive
     // blocks finish.  Starting blocks in order of decreasing cost (coarse buckets, so that neighbours stay
-    // together) removes most of that tail: Scene1 3.40 -> 3.22 ms, config 4 19.6 -> 18.4 ms.  Costs are
-    // the blocks' ray counts of an earlier launch of the same grid, copied back asynchronously and only
+    // together) removes most of that tail: Scene1 3.39 -> 3.25 ms, config 4 19.7 -> 17.5 ms.  Costs are
+    // the blocks' wave-cycles in an earlier launch of the same grid, copied back asynchronously and only
     // polled — a launch never waits for them, and any order gives the same image.
     static const bool order_env = [] {
         const char* v = getenv("SRT_LPT");
@@ -595,7 +595,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             // keeps the spatial order inside a bucket
             static const int NB = [] {
                 const char* v = getenv("SRT_LPT_BUCKETS");
-                int b = v ? atoi(v) : 32;
+                int b = v ? atoi(v) : 128;
                 return b < 2 ? 2 : (b > 4096 ? 4096 : b);
             }();
             // a launch whose blocks all cost about the same (5th..95th percentile within 1.5x) keeps the

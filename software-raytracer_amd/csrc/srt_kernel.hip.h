@@ -86,7 +86,7 @@ struct KernelParams {
     float4* sample_rows;     // [tile][sample][64 slots] sample colours
     unsigned long long* tile_masks;  // [tile] which pixels of the tile are traced (slot k = k-th set bit)
     // cost-ordered dispatch: workgroup i of the launch works on tile block wg_order[i] (NULL: i); every
-    // wave adds its ray count to wg_cost[block] (NULL: not recorded) for the order of the next launch
+    // wave adds its run time (cycles / 256) to wg_cost[block] (NULL: not recorded) for the order of the next launch
     const uint32_t* wg_order;
     uint32_t* wg_cost;
     float4* accumulator;
@@ -756,6 +756,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     const int tile_h = P.tile_h;
     // which block of tiles: the hardware starts workgroups in linear order, wg_order maps that order to
     // blocks sorted by decreasing cost so that the expensive ones do not end up in the tail
+    const long long t_start = P.wg_cost ? (long long)__builtin_readcyclecounter() : 0;
     uint32_t block_id = blockIdx.y * gridDim.x + blockIdx.x;
     if (P.wg_order) block_id = P.wg_order[block_id];
     const int bx = (int)(block_id % gridDim.x), by = (int)(block_id / gridDim.x);
@@ -1049,7 +1050,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
         if (lane == 0 && tot) {
             if (P.flags & 2u) atomicAdd(P.ray_counter, tot);
-            if (P.wg_cost) atomicAdd(&P.wg_cost[block_id], (uint32_t)(tot > 0xFFFFFFFFull ? 0xFFFFFFFFull : tot));
+            if (P.wg_cost) atomicAdd(&P.wg_cost[block_id], (uint32_t)(((long long)__builtin_readcyclecounter() - t_start) >> 8));
         }
     }
 }
