@@ -587,7 +587,9 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             if (!ctx->ev_order) SRT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
             ctx->wg_capacity = nwg;
         }
-        if (ctx->recording && hipEventQuery(ctx->ev_cost) == hipSuccess) {  // costs have arrived: make the order
+        const hipError_t arrived = ctx->recording ? hipEventQuery(ctx->ev_cost) : hipErrorNotReady;
+        if (arrived != hipSuccess) (void)hipGetLastError();  // "not ready" must not surface as this launch's error
+        if (arrived == hipSuccess) {  // costs have arrived: make the order
             ctx->recording = false;
             const size_t n = (size_t)ctx->rec_gx * ctx->rec_gy;
             if (ctx->order_gx) (void)hipEventSynchronize(ctx->ev_order);  // (long done) the previous upload read h_wg_order
