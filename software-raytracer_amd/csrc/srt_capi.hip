@@ -747,6 +747,7 @@ int srt_poll(srt_context* ctx, int* done) {
         return SRT_OK;
     }
     if (e == hipErrorNotReady) {
+        (void)hipGetLastError();  // not an error: keep it from surfacing in a later hipGetLastError()
         *done = 0;
         return SRT_OK;
     }

@@ -317,3 +317,22 @@ def test_sample_chunks_extremes(srt, oracle):
     assert np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32))
     assert np.array_equal(pt.framebuffer(rows=(10, 150)), ofb[10:150])
     pt.close()
+
+
+def test_poll_while_busy_then_render_again(srt):
+    """srt_poll on a running launch reports "not done" without poisoning the next call: HIP's not-ready
+    status must not come back from hipGetLastError() as that launch's error (same for the internal poll
+    of the block-cost feedback)."""
+    pt, objs, n = _pt(srt, "Scene_indirect", 1920, 1080)
+    pt.render(spp=32, bounces=8, seed=0)   # ~20 ms on an MI355X
+    first = pt.poll()
+    pt.render(spp=1, bounces=8, seed=0)    # enqueued behind it; must not fail
+    second = pt.poll()
+    pt.render(spp=1, bounces=8, seed=0)
+    pt.wait()
+    assert pt.poll() is True
+    assert first is False or second is False or True  # timing-dependent; the calls above not raising is the test
+    a = pt.framebuffer()
+    pt.render(spp=1, bounces=8, seed=0)
+    assert np.array_equal(pt.framebuffer(), a)
+    pt.close()
