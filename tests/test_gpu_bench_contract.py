@@ -1,0 +1,47 @@
+"""bench.py's output contract (one JSON line, the driver's keys, `roofline` and `cpu_baseline` objects),
+on a small workload, and the multi-rank control flow rehearsed with two ranks sharing the GPU over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(stdout):
+    lines = [l for l in stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--width", "480", "--height", "270",
+                        "--spp", "4", "--cpu-spp", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "path-samples/s" and d["dtype"] == "f32" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 480 * 270 * 4 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"] and cb["sample"]
+    assert cb["parity_bit_exact"] is True  # the GPU frame and the oracle's frame of the same sample are identical
+
+
+def test_two_rank_rehearsal():
+    env = dict(os.environ, SRT_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--width", "640", "--height", "360", "--spp", "8"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["stripe_parity_vs_single_device"] is True
+    bands = d["config"]["bands"]
+    assert bands[0][0] == 0 and bands[-1][1] == 360 and bands[0][1] == bands[1][0]
+    assert len(d["per_rank"]) == 2
