@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel per GPU-share (x N for N GPUs)")
     ap.add_argument("--bounces", type=int, default=BOUNCES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU sample")
+    ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the bounded CPU sample (16 spp at 1080p = about 20 s of CPU work)")
     ap.add_argument("--balance", default="cost", choices=["cost", "equal"], help="row-stripe split for N>1")
     ap.add_argument("--gather", default="p2p", choices=["p2p", "padded"],
                     help="how cost-balanced (unequal) bands are joined: one grouped isend/irecv in place, or one padded dist.gather")
