@@ -87,7 +87,10 @@ typedef struct srt_object {
  * (binary32 add); Moller-Trumbore in binary32 without FMA in a fixed operation order; a hit is
  * valid for 0.01 <= t <= 10000 (the Box bounds, Object.hpp:226); the normal is the unit geometric
  * normal turned against the ray.  Among equal distances the earlier object in ObjectsToRender
- * wins, then the lower triangle index.  Vertices: 3 floats each; indices: 3 uint32 per triangle. */
+ * wins, then the lower triangle index.  Vertices: 3 floats each; indices: 3 uint32 per triangle.
+ * Limits (srt_set_scene fails with SRT_ERR_INVALID_ARG beyond them): 20 M triangles per mesh, 16 M in a
+ * scene, world coordinates of magnitude <= 1e9, BVH depth <= 72 levels.  Triangles with an index out of
+ * range or a non-finite vertex are ignored (they cannot produce a valid hit). */
 typedef struct srt_mesh {
     const float* vertices;
     size_t vertex_count;
@@ -121,7 +124,9 @@ typedef struct srt_camera {
                                      instead of the path-traced branch (:162-185)           */
 
 /* One render call = sample_count successive "frames" of the reference's loop over a
- * band of memory rows, all on the device, accumulator kept in registers in between.
+ * band of memory rows, all on the device, accumulator kept in registers in between
+ * (or, for launches with many samples per pixel, the sample colours kept in device memory and folded
+ * in order by a second kernel — INTEGRATION.md §6; the result bits are the same).
  *   sample f (1-based, = ACCUMULATIONFRAMES) keys the RNG and sets the running-mean
  *   weight w = (float)(1.0 / f)               (Raytracer.cpp:66-67).
  *   Clean sequence: first_sample = 1 with SRT_RENDER_RESET, later calls continue with
@@ -146,7 +151,7 @@ typedef struct srt_render_params {
 typedef struct srt_stats {
     uint64_t rays;          /* GetClosestObject calls (primary counted once per sample) */
     uint64_t path_samples;  /* W_band * H_band * sample_count of the last render */
-    float kernel_ms;        /* HIP-event time of the last render's kernel on its stream */
+    float kernel_ms;        /* HIP-event time of the last render's kernel(s) on its stream */
 } srt_stats;
 
 typedef struct srt_context srt_context;
