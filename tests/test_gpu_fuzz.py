@@ -32,6 +32,9 @@ def _random_scene(oracle, rng, kind):
         V[1::3] = V[0::3] + (rng.uniform(-0.5, 0.5, (nt, 3)) * scale).astype(np.float32)
         V[2::3] = V[0::3] + (rng.uniform(-0.5, 0.5, (nt, 3)) * scale).astype(np.float32)
         T = np.arange(3 * nt, dtype=np.uint32).reshape(nt, 3)
+        if rng.uniform() < 0.25:  # broken input: an index out of range, a non-finite vertex — such triangles never hit
+            T[int(rng.integers(0, nt)), int(rng.integers(0, 3))] = 3 * nt + int(rng.integers(0, 1000))
+            V[int(rng.integers(0, 3 * nt)), int(rng.integers(0, 3))] = [np.inf, -np.inf, np.nan][int(rng.integers(0, 3))]
         meshes.append((V, T))
         for _ in range(int(rng.integers(1, 3))):
             p = off + rng.uniform(-2, 2, 3) * scale
