@@ -10,8 +10,9 @@
 // Two back ends share ViewerCore:
 //   * headless (always built, tested): input comes from a script, frames go to PPM files;
 //   * SDL2 window (compiled only when the Makefile finds SDL2 through pkg-config, -DSRT_WITH_SDL2 —
-//     this image has no SDL2, so that part has never been compiled here; it follows the same
-//     ViewerCore calls the headless back end exercises).
+//     this image has no SDL2, so that part has only been syntax-checked against hand-written
+//     declarations, never linked or run; it makes the same ViewerCore calls the headless back end
+//     exercises).
 // The reference's ImGui inspector (vendored Dear ImGui) is not reproduced; its settings are on keys.
 //
 // Input semantics mirrored from the reference (citations: Raytracer.cpp):
