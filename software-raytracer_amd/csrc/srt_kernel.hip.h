@@ -101,7 +101,7 @@ constexpr int WG_W = TILE_W * WG_TILES_X, WG_H = TILE_H * WG_TILES_Y;
 // per-wave LDS scratch behind the scene image: work list of (ray lane, cluster) items + one
 // 64-bit result slot per lane (balanced phase 2 of closest_hit)
 constexpr int WORK_MAX = 512;
-constexpr int RING_DEPTH = 4;  // ring entries per slot when all 64 pixels of the tile are traced
+constexpr int RING_DEPTH = 4;  // ring entries per slot when all 64 pixels of the tile are traced (power of two)
 // per-wave: 64 result slots (8 B) | work list (2 B) | 64 pixel records (48 B) | ring (16 B)
 constexpr int WAVE_SCRATCH_BYTES = 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4 + 64 * RING_DEPTH * 16;
 constexpr int WG_SCRATCH_BYTES = WAVE_SCRATCH_BYTES * WG_TILES_X * WG_TILES_Y;
@@ -112,6 +112,18 @@ __device__ unsigned long long g_stats[8];
 #define SRT_STAT(i, v) do { if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
 #else
 #define SRT_STAT(i, v) do { } while (0)
+#endif
+#if defined(SRT_STATS) && SRT_STATS == 3  // make STATS=3: wave-cycles per section of the pool loop (tests/section_profile.py)
+struct Prof {
+    long long last, acc[8];
+};
+#define SRT_PROF_PARAM , Prof& prof
+#define SRT_PROF_ARG , prof
+#define SRT_TICK(i) do { const long long now_ = (long long)__builtin_readcyclecounter(); prof.acc[i] += now_ - prof.last; prof.last = now_; } while (0)
+#else
+#define SRT_PROF_PARAM
+#define SRT_PROF_ARG
+#define SRT_TICK(i) do { } while (0)
 #endif
 constexpr int MESH_WAVE_BYTES = (MESH_QN + MESH_QL) * 4;
 constexpr int WG_MESH_SCRATCH_BYTES = MESH_WAVE_BYTES * WG_TILES_X * WG_TILES_Y;
@@ -233,7 +245,7 @@ __device__ __forceinline__ void hit_unkey(unsigned long long k, float& t, int& p
 //      LDS atomicMin on hit_key — so the wave does sum(pairs)/64 rounds, not max-per-lane.
 //   3. boxes: every lane, exact arithmetic.
 template <bool MESH>
-__device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, V3 o, V3 d, bool active, int defer_min, bool& deferred) {
+__device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, V3 o, V3 d, bool active, int defer_min, bool& deferred SRT_PROF_PARAM) {
     float best = __builtin_inff();
     int bp = -1;
     // exact sphere test of ray (ro, rd) against four spheres; updates (tb, pb) with the tie rule.
@@ -275,11 +287,13 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             part2(k3, p + 3, tb, pb);
         }
     };
+    SRT_TICK(2);
     // ---- 1. uniform spheres: broadcast ds_read_b128, 4 per trip
     for (int j = 0; j < S.nu4; j += 4) {
         const float4 s0 = S.v[j], s1 = S.v[j + 1], s2 = S.v[j + 2], s3 = S.v[j + 3];
         test4(s0, s1, s2, s3, j, o, d, active, best, bp);
     }
+    SRT_TICK(3);
     // ---- 2. clustered spheres
     if (S.nc > 0) {
         const float dd = __builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x));
@@ -308,6 +322,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                 total += __builtin_popcountll(bal) << b;
             }
             total = __builtin_amdgcn_readfirstlane(total);
+            SRT_TICK(4);
             if (total > 0 && total <= WORK_MAX) {
                 const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
                 // the lane's own best so far enters the merge slot
@@ -361,6 +376,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             }
         }
     }
+    SRT_TICK(5);
     // ---- 3. boxes
     Hit h;
     V3 bt1 = v3(0, 0, 0);
@@ -636,6 +652,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
     } else {
         h.n = v3(0, 0, 0);
     }
+    SRT_TICK(6);
     return h;
 }
 
@@ -742,6 +759,11 @@ __device__ __forceinline__ Lds make_lds(const KernelParams& P, float4* lds, int 
 template <int MIN_WAVES, bool MESH, bool SCENE_LDS = true, bool MULTI = false, bool DEFER = false>
 __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const KernelParams P) {
     extern __shared__ float4 lds_scene[];
+#if defined(SRT_STATS) && SRT_STATS == 3
+    Prof prof;
+    prof.last = (long long)__builtin_readcyclecounter();
+    for (int i = 0; i < 8; ++i) prof.acc[i] = 0;
+#endif
     if constexpr (SCENE_LDS) {  // stage the scene image into LDS (coalesced 16-byte loads)
         for (int i = threadIdx.x; i < P.scene_vec4; i += WG_THREADS) lds_scene[i] = P.scene[i];
         __syncthreads();
@@ -787,7 +809,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
 
     // ---- primary hit: identical for every sample ------------------------------------
     bool parked = false;  // path pool: this lane's ray waits for a mesh phase (see closest_hit)
-    const Hit h0 = closest_hit<MESH>(S, P, cam, dir0, true, 1, parked);
+    const Hit h0 = closest_hit<MESH>(S, P, cam, dir0, true, 1, parked SRT_PROF_ARG);
 
     const bool reset = (P.flags & 1u) != 0;
     // samples of this workgroup: all of them, or chunk blockIdx.z of the launch
@@ -896,6 +918,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         int rot = 0;  // wave-uniform rotation of the slot priority
 
         while (true) {
+            SRT_TICK(7);
             // ---- fold finished samples, in order, into the owners' running means
             for (int it = 0; it < depth; ++it) {
                 bool ready = false;
@@ -915,6 +938,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             }
             if (__builtin_amdgcn_ballot_w64(own_done < count) == 0ull) break;  // every slot finished
 
+            SRT_TICK(0);
             // ---- hand out tasks: the i-th free lane takes the next sample of the i-th slot that has ring
             // capacity (ballot ranks on both sides, matched through S.work).  MULTI: when there are more
             // free lanes than such slots, the lanes are dealt round-robin to the slots and a slot hands out
@@ -982,6 +1006,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 __builtin_amdgcn_wave_barrier();
             }
 
+            SRT_TICK(1);
             // ---- one bounce for every busy lane
             V3 o = v3(0, 0, 0);
             const float ofs = .00001f;
@@ -1010,7 +1035,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 o = v3(hp.x + hn.x * ofs, hp.y + hn.y * ofs, hp.z + hn.z * ofs);  // :177
             }
             // the scan runs in wave-uniform control flow: idle lanes help with other lanes' rays
-            const Hit h = closest_hit<MESH>(S, P, o, sray, busy, P.mesh_defer, parked);
+            const Hit h = closest_hit<MESH>(S, P, o, sray, busy, P.mesh_defer, parked SRT_PROF_ARG);
             if (busy && !(MESH && parked)) {
                 ++rays;
                 bool end_path;
@@ -1045,6 +1070,10 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         if (!DEFER && owner) write_pixel(own_pixel, acc);
     }
 
+#if defined(SRT_STATS) && SRT_STATS == 3
+    SRT_TICK(7);
+    for (int i = 0; i < 8; ++i) SRT_STAT(i, prof.acc[i] > 0 ? prof.acc[i] : 0);
+#endif
     if ((P.flags & 2u) || P.wg_cost) {  // SRT_RENDER_COUNT_RAYS / cost feedback for the dispatch order
         unsigned long long tot = rays;
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
@@ -1106,7 +1135,10 @@ __global__ void __launch_bounds__(64) pick_kernel(const KernelParams P, int px, 
     V3 vv = v3(P.up_ld[0] * nY, P.up_ld[1] * nY, P.up_ld[2] * nY);
     const V3 dir = normalized(v3((u.x + vv.x) + P.fwd_clip[0], (u.y + vv.y) + P.fwd_clip[1], (u.z + vv.z) + P.fwd_clip[2]));
     bool deferred = false;
-    const Hit h = closest_hit<true>(S, P, v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]), dir, true, 1, deferred);
+#if defined(SRT_STATS) && SRT_STATS == 3
+    Prof prof{};
+#endif
+    const Hit h = closest_hit<true>(S, P, v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]), dir, true, 1, deferred SRT_PROF_ARG);
     if (threadIdx.x == 0) {
         out_index[0] = h.prim >= 0 ? S.order(h.prim) : -1;
         out_index[1] = __float_as_int(h.t);

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Development aid: where the waves of pathtrace_kernel spend their cycles (library built with `make STATS=3`).
+usage: python tests/section_profile.py [--scene Scene1] [--spp 32] [--mesh 0]"""
+import argparse, ctypes as C, importlib, json, os, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument("--scene", default="Scene1")
+ap.add_argument("--spp", type=int, default=32)
+ap.add_argument("--bounces", type=int, default=8)
+ap.add_argument("--mesh", type=int, default=0)
+a = ap.parse_args()
+srt = importlib.import_module("software-raytracer_amd")
+L = srt.load_library()
+path = os.path.join(ROOT, "software-raytracer_amd", "scenes", a.scene + ".json")
+if a.mesh:
+    sj = json.load(open(path))
+    sj["SceneObjects"][64]["Renderer"] = {"Type": "Mesh", "Primitive": "UVSphere", "Radius": 1.0, "Stacks": a.mesh, "Slices": a.mesh}
+    tmp = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False); json.dump(sj, tmp); tmp.close(); path = tmp.name
+sc = srt.host.Scene(path)
+objs, n = sc.objects_copy(); meshes, nm = sc.meshes()
+pt = srt.PathTracer(1920, 1080)
+pt.set_meshes(meshes, nm); pt.set_scene(objs, n); pt.set_camera(srt.default_camera())
+out = (C.c_ulonglong * 8)()
+pt.render(spp=a.spp, bounces=a.bounces, seed=0); pt.stats(); L.srt_debug_read_stats(out)
+pt.render(spp=a.spp, bounces=a.bounces, seed=0, count_rays=True); st = pt.stats(); L.srt_debug_read_stats(out)
+names = ["fold (ordered running mean)", "task hand-out", "ray generation (+ prologue)", "phase 1: uniform spheres", "phase 2: cluster bounds + compaction",
+         "phase 2: exact rounds + merge", "boxes + mesh + hit point/normal", "shade + environment + misc"]
+tot = sum(out) or 1
+print("%s spp %d: kernel %.3f ms, rays %d" % (a.scene, a.spp, st.kernel_ms, st.rays))
+for k, v in zip(names, out): print("  %-40s %5.1f %%" % (k, 100.0 * v / tot))
