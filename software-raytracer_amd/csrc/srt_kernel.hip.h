@@ -271,8 +271,11 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             // Raytracer.cpp:130-132; on an exact tie the earlier entry of ObjectsToRender wins.
             // Branch-free on purpose (see the note in the triangle phase).
             const bool tie = k.c & (t1 == tb) & (pb >= 0);
-            const int op = S.order(p), ob = S.order(tie ? pb : p);
-            const bool win = k.c & ((t1 < tb) | (tie & (op < ob)));
+            bool win = k.c & (t1 < tb);
+            if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // rare: only then are the list indices needed (two LDS reads)
+                const int op = S.order(p), ob = S.order(tie ? pb : p);
+                win = win | (tie & (op < ob));
+            }
             tb = win ? t1 : tb;
             pb = win ? p : pb;
         }
@@ -391,8 +394,11 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             bool valid = active && dist != 3.402823466e+38f;  // Object.hpp:231
             if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
                 const bool tie = valid & (dist == best) & (bp >= 0);
-                const int ob = S.order(tie ? bp : nsT + j);
-                const bool win = valid & ((dist < best) | (tie & (S.order(nsT + j) < ob)));
+                bool win = valid & (dist < best);
+                if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // rare: list indices only on an exact tie
+                    const int ob = S.order(tie ? bp : nsT + j);
+                    win = win | (tie & (S.order(nsT + j) < ob));
+                }
                 best = win ? dist : best;
                 bp = win ? nsT + j : bp;
                 // component-wise: a whole-struct select is lowered to a pointer select + copies through scratch
