@@ -895,6 +895,9 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             r[11] = __uint_as_float(pixel);
         }
         const int depth = (64 * RING_DEPTH) / n_hit;  // ring entries per slot (>= RING_DEPTH)
+        // sample -> ring row: a mask when depth is a power of two (full tiles: 4), else a real modulo (~20 instructions)
+        const bool depth_pow2 = (depth & (depth - 1)) == 0;
+        auto ring_row = [&](uint32_t s) { return depth_pow2 ? (s & (uint32_t)(depth - 1)) : (s % (uint32_t)depth); };
         float4* ring = S.ring;                        // [depth][n_hit] of (r, g, b, tag)
         for (int i = lane; i < 64 * RING_DEPTH; i += 64) ring[i] = make_float4(0, 0, 0, __uint_as_float(0xFFFFFFFFu));
         __builtin_amdgcn_wave_barrier();
@@ -930,7 +933,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 bool ready = false;
                 float4 e = make_float4(0, 0, 0, 0);
                 if (own_done < count) {
-                    e = ring[(own_done % (uint32_t)depth) * n_hit + lane];
+                    e = ring[ring_row(own_done) * n_hit + lane];
                     ready = __float_as_uint(e.w) == own_done;
                 }
                 if (__builtin_amdgcn_ballot_w64(ready) == 0ull) break;
@@ -1067,7 +1070,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 }
                 if (end_path) {  // hand the sample colour to the slot's owner
                     const uint32_t sidx = task >> 6;
-                    ring[(sidx % (uint32_t)depth) * n_hit + (int)(task & 63u)] = make_float4(L.r, L.g, L.b, __uint_as_float(sidx));
+                    ring[ring_row(sidx) * n_hit + (int)(task & 63u)] = make_float4(L.r, L.g, L.b, __uint_as_float(sidx));
                     busy = false;
                 }
             }
