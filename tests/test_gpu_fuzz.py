@@ -11,8 +11,10 @@ pytestmark = pytest.mark.gpu
 
 def _random_scene(oracle, rng, kind):
     objs, meshes = [], []
-    scale = {"unit": 1.0, "far": 1.0e4, "tiny": 1.0e-2, "mixed": 1.0}[kind]
-    off = np.array({"unit": (0, 0, 6), "far": (3.0e4, -2.0e4, 5.0e4), "tiny": (0, 0, 0.06), "mixed": (0, 0, 6)}[kind])
+    # "offset": unit-sized geometry 50 000 units from the origin — coordinates carry only ~8 significant bits
+    # of the object sizes, which is where absolute-magnitude rounding would break a non-conservative cull
+    scale = {"unit": 1.0, "far": 1.0e4, "tiny": 1.0e-2, "mixed": 1.0, "offset": 1.0}[kind]
+    off = np.array({"unit": (0, 0, 6), "far": (3.0e4, -2.0e4, 5.0e4), "tiny": (0, 0, 0.06), "mixed": (0, 0, 6), "offset": (2.5e4, -1.5e4, 4.0e4)}[kind])
     n_sph = int(rng.integers(0, 90))
     for _ in range(n_sph):
         r = float(rng.uniform(0.02, 0.6) * scale)
@@ -52,7 +54,7 @@ import os
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SRT_FUZZ_N", "24"))))
 def test_random_scene_parity(srt, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
-    kind = ["unit", "far", "tiny", "mixed"][seed % 4]
+    kind = ["unit", "far", "tiny", "mixed", "offset"][seed % 5]
     objs, meshes, off, scale = _random_scene(oracle, rng, kind)
     oarr, n = oracle.make_objects(objs)
     marr, mn, keep = oracle.make_meshes(meshes)
