@@ -80,6 +80,7 @@ struct srt_context {
     unsigned rec_gx = 0, rec_gy = 0;      // grid of the recording in flight
     bool recording = false;               // a cost copy is in flight (ev_cost)
     bool order_stale = true;              // scene / camera changed since the costs were recorded
+    bool order_disabled = false;          // buffers for the feedback could not be allocated
     hipEvent_t ev_cost = nullptr, ev_order = nullptr;
 
     srt_environment env;
@@ -568,7 +569,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     }();
     bool record = false;
     const size_t nwg = (size_t)grid.x * grid.y;
-    if (order_env && nwg >= 2048 && p->sample_count >= 4 && !(p->flags & SRT_RENDER_PREVIEW)) {
+    if (order_env && !ctx->order_disabled && nwg >= 2048 && p->sample_count >= 4 && !(p->flags & SRT_RENDER_PREVIEW)) {
         if (nwg > ctx->wg_capacity) {
             SRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->d_wg_cost) (void)hipFree(ctx->d_wg_cost);
@@ -579,14 +580,22 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             ctx->wg_capacity = 0;
             ctx->order_gx = ctx->order_gy = 0;
             ctx->recording = false;
-            SRT_HIP(ctx, hipMalloc((void**)&ctx->d_wg_cost, nwg * 4));
-            SRT_HIP(ctx, hipMalloc((void**)&ctx->d_wg_order, nwg * 4));
-            SRT_HIP(ctx, hipHostMalloc((void**)&ctx->h_wg_cost, nwg * 4, hipHostMallocDefault));
-            SRT_HIP(ctx, hipHostMalloc((void**)&ctx->h_wg_order, nwg * 4, hipHostMallocDefault));
-            if (!ctx->ev_cost) SRT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_cost, hipEventDisableTiming));
-            if (!ctx->ev_order) SRT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
-            ctx->wg_capacity = nwg;
+            // an optimisation must not be able to fail a render: if anything here cannot be had (pinned host
+            // memory, for one), the handle simply keeps the natural order from now on
+            const bool ok = hipMalloc((void**)&ctx->d_wg_cost, nwg * 4) == hipSuccess && hipMalloc((void**)&ctx->d_wg_order, nwg * 4) == hipSuccess &&
+                            hipHostMalloc((void**)&ctx->h_wg_cost, nwg * 4, hipHostMallocDefault) == hipSuccess &&
+                            hipHostMalloc((void**)&ctx->h_wg_order, nwg * 4, hipHostMallocDefault) == hipSuccess &&
+                            (ctx->ev_cost || hipEventCreateWithFlags(&ctx->ev_cost, hipEventDisableTiming) == hipSuccess) &&
+                            (ctx->ev_order || hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming) == hipSuccess);
+            if (ok) {
+                ctx->wg_capacity = nwg;
+            } else {
+                (void)hipGetLastError();
+                ctx->order_disabled = true;
+            }
         }
+    }
+    if (order_env && !ctx->order_disabled && ctx->wg_capacity >= nwg && nwg >= 2048 && p->sample_count >= 4 && !(p->flags & SRT_RENDER_PREVIEW)) {
         const hipError_t arrived = ctx->recording ? hipEventQuery(ctx->ev_cost) : hipErrorNotReady;
         if (arrived != hipSuccess) (void)hipGetLastError();  // "not ready" must not surface as this launch's error
         if (arrived == hipSuccess) {  // costs have arrived: make the order
