@@ -119,6 +119,23 @@ def build_native(force=False):
 _lib = None
 
 
+def use_dev_library(stats=None, rebuild=False):
+    """Development tools only (tests/ab_bench.py, tests/mesh_stats.py, tools/): build and select
+    libsrt_pathtrace_dev.so (-DSRT_DEV: environment switches, srt_debug_* entry points, optional STATS
+    counters).  Must be called before the first load_library(); the product and the tests never call it."""
+    global _LIB
+    assert _lib is None, "use_dev_library() must come before load_library()"
+    dev = os.path.join(_PKG, "libsrt_pathtrace_dev.so")
+    args = ["make", "-C", os.path.join(_PKG, "csrc"), "-s", "dev"]
+    if stats is not None:
+        args += ["STATS=%d" % stats, "-B"]
+    elif rebuild:
+        args.append("-B")
+    subprocess.check_call(args)
+    _LIB = dev
+    return dev
+
+
 def load_library():
     """dlopen libsrt_pathtrace.so and declare prototypes. Raises SrtError if it is absent."""
     global _lib

@@ -25,6 +25,43 @@ namespace {
 
 thread_local char g_create_error[512] = "";
 
+// Tuning switches.  The shipped library has none: every value below is a constant.  A development build
+// (make -C software-raytracer_amd/csrc dev -> libsrt_pathtrace_dev.so, -DSRT_DEV) reads them from the
+// environment for in-process A/B timing (tests/ab_bench.py); all settings produce identical bits.
+struct DevSwitches {
+    int kernel = 0;        // SRT_KERNEL: tuning variant
+    bool no_cluster = false;  // SRT_NO_CLUSTER
+    int tile_h = 0;        // SRT_TILE_H: 8/4/2/1 forces the tile height
+    int defer = -1;        // SRT_DEFER: 0 never chunk samples, n > 0 force n samples per chunk
+    bool lpt = true;       // SRT_LPT=0: natural dispatch order
+    int lpt_buckets = 128; // SRT_LPT_BUCKETS
+    bool host_order = true;  // SRT_HOST_ORDER=0: no host-derived initial dispatch order
+};
+#ifdef SRT_DEV
+const DevSwitches& dev_switches() {
+    static const DevSwitches sw = [] {
+        DevSwitches d;
+        auto geti = [](const char* name, int dflt) {
+            const char* v = getenv(name);
+            return v ? atoi(v) : dflt;
+        };
+        d.kernel = geti("SRT_KERNEL", 0);
+        d.no_cluster = getenv("SRT_NO_CLUSTER") != nullptr;
+        d.tile_h = geti("SRT_TILE_H", 0);
+        d.defer = geti("SRT_DEFER", -1);
+        d.lpt = geti("SRT_LPT", 1) != 0;
+        int b = geti("SRT_LPT_BUCKETS", 128);
+        d.lpt_buckets = b < 2 ? 2 : (b > 4096 ? 4096 : b);
+        d.host_order = geti("SRT_HOST_ORDER", 1) != 0;
+        return d;
+    }();
+    return sw;
+}
+#else
+constexpr DevSwitches k_dev_switches{};
+constexpr const DevSwitches& dev_switches() { return k_dev_switches; }
+#endif
+
 struct HostCamera {
     srt_camera cam;
     bool set = false;
@@ -254,7 +291,7 @@ static int set_scene_impl(srt_context* ctx, const srt_object* objects, size_t co
     // from here on the context holds no scene until this call completes: a failure below must not leave
     // a half-replaced one (new image, freed BVH) for srt_render to launch on
     ctx->scene_set = false;
-    static const bool no_cluster = getenv("SRT_NO_CLUSTER") != nullptr;
+    const bool no_cluster = dev_switches().no_cluster;
     bool has_mesh = false;
     for (size_t i = 0; i < count; ++i) has_mesh = has_mesh || objects[i].type == SRT_OBJ_MESH;
     for (int v = 0; v < 2; ++v) {
@@ -280,7 +317,15 @@ static int set_scene_impl(srt_context* ctx, const srt_object* objects, size_t co
                                     hipMemcpyHostToDevice, ctx->stream));
         ctx->layout[v] = L;
     }
-    // EXTENSION: flatten mesh objects into a world-space triangle list + BVH (HBM resident)
+    // EXTENSION: flatten mesh objects into a world-space triangle list + BVH (HBM resident).  The size limits
+    // of the device encoding (24-bit triangle ids, 26-bit node ids) are checked BEFORE the build and the uploads.
+    {
+        unsigned long long total_tris = 0;
+        for (size_t i = 0; i < count; ++i)
+            if (objects[i].type == SRT_OBJ_MESH) total_tris += ctx->meshes[(size_t)objects[i].mesh].indices.size() / 3;
+        if (total_tris >= (1ull << 24))
+            return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: %llu mesh triangles exceed the limit of 2^24 - 1 per scene", total_tris);
+    }
     srt::build_mesh_image(objects, count, ctx->meshes, ctx->layout[0].nsT + ctx->layout[0].nb, ctx->mesh_image);
     if (ctx->d_bvh_nodes) SRT_HIP(ctx, hipFree(ctx->d_bvh_nodes));
     if (ctx->d_bvh_tris) SRT_HIP(ctx, hipFree(ctx->d_bvh_tris));
@@ -291,6 +336,8 @@ static int set_scene_impl(srt_context* ctx, const srt_object* objects, size_t co
         // strict depth-first traversal (the kernel's last resort) keeps at most 7 entries per level
         if (7 * ctx->mesh_image.max_depth + 8 > srt::MESH_QN)
             return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: BVH too deep (%d levels)", ctx->mesh_image.max_depth);
+        if (ctx->mesh_image.n_nodes >= (1 << 26) || ctx->mesh_image.n_tris >= (1 << 24))  // (item encoding of the traversal queues)
+            return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: mesh too large (%d triangles)", ctx->mesh_image.n_tris);
         for (int ax = 0; ax < 3; ++ax)  // keeps cell * slope finite in the kernel's plane distances
             if (!(fabsf(ctx->mesh_image.center[ax]) + ctx->mesh_image.half[ax] <= 1e9f))
                 return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: mesh coordinates beyond 1e9 are not supported");
@@ -303,8 +350,6 @@ static int set_scene_impl(srt_context* ctx, const srt_object* objects, size_t co
         SRT_HIP(ctx, hipMalloc((void**)&ctx->d_bvh_gidpos, ctx->mesh_image.gidpos.size() * sizeof(int32_t)));
         SRT_HIP(ctx, hipMemcpyAsync(ctx->d_bvh_gidpos, ctx->mesh_image.gidpos.data(), ctx->mesh_image.gidpos.size() * sizeof(int32_t),
                                     hipMemcpyHostToDevice, ctx->stream));
-        if (ctx->mesh_image.n_nodes >= (1 << 26) || ctx->mesh_image.n_tris >= (1 << 24))
-            return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: mesh too large (%d triangles)", ctx->mesh_image.n_tris);
     }
     ctx->scene_set = true;
     ctx->order_stale = true;
@@ -332,7 +377,8 @@ static int set_meshes_impl(srt_context* ctx, const srt_mesh* meshes, size_t coun
         const srt_mesh& m = meshes[i];
         if ((m.vertex_count && !m.vertices) || (m.triangle_count && !m.indices))
             return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_meshes: mesh %zu has NULL arrays", i);
-        if (m.triangle_count > (size_t)20000000) return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_meshes: mesh %zu is too large", i);
+        if (m.triangle_count >= ((size_t)1 << 24))  // the same limit srt_set_scene applies to the scene's total
+            return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_meshes: mesh %zu has %zu triangles, the limit is 2^24 - 1", i, m.triangle_count);
         copy[i].vertices.assign(m.vertices, m.vertices + 3 * m.vertex_count);
         copy[i].indices.assign(m.indices, m.indices + 3 * m.triangle_count);
     }
@@ -428,11 +474,7 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
     K.steps = p->steps > 1 ? p->steps : 1;
     K.stripe_width = p->stripe_width > 0 ? p->stripe_width : 0;
     K.selected = p->selected_object;
-    static const int variant = [] {
-        const char* v = getenv("SRT_KERNEL");
-        return v ? atoi(v) : 0;
-    }();
-    use = ctx->variant >= 0 ? ctx->variant : variant;
+    use = ctx->variant >= 0 ? ctx->variant : dev_switches().kernel;
     img = (use == 2) ? 1 : 0;  // variant 2: plain brute-force image
     K.mesh_defer = use >= 100 ? use - 100 : 16;  // variants 100 + n: mesh phases wait for n rays
     const srt::SceneLayout& SL = ctx->layout[img];
@@ -493,10 +535,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     // tiles give too few workgroups to fill 256 CUs x 4 resident workgroups and leave nothing to balance
     // the tail with; halve the tile (twice the workgroups, same lanes at work in each wave's path pool)
     // until there are about four rounds of workgroups.  Results do not depend on the tiling.
-    static const int tile_env = [] {
-        const char* v = getenv("SRT_TILE_H");
-        return v ? atoi(v) : 0;
-    }();
+    const int tile_env = dev_switches().tile_h;
     int tile_h = srt::TILE_H;
     const long long wg_x = (W + srt::WG_W - 1) / srt::WG_W;
     const long long want = 15LL * ctx->cu_count;  // ~4 rounds of the 4 workgroups a CU holds; measured on bands of 30..400 rows
@@ -509,10 +548,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     // few long ones whose tail idles the chip: 135 rows x 256 spp 4.9 ms -> 2.2 ms, and still ~10 % on a
     // full 1080p frame at 256 spp.  Costs 1 KiB of HBM per tile and sample (falls back to small tiles
     // when that is not available).
-    static const int defer_env = [] {
-        const char* v = getenv("SRT_DEFER");
-        return v ? atoi(v) : -1;  // 0: never, n > 0: force n samples per chunk
-    }();
+    const int defer_env = dev_switches().defer;  // 0: never, n > 0: force n samples per chunk
     const long long wg_y8 = (K.rows + srt::WG_H - 1) / srt::WG_H, wg8 = wg_x * wg_y8;
     int chunk = 0, chunks = 1;
     // (scenes with meshes from 32 spp: their few, heavy tiles profit earlier — config 4 at 32 spp +20 %)
@@ -563,10 +599,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     // together) removes most of that tail: Scene1 3.39 -> 3.25 ms, config 4 19.7 -> 17.5 ms.  Costs are
     // the blocks' wave-cycles in an earlier launch of the same grid, copied back asynchronously and only
     // polled — a launch never waits for them, and any order gives the same image.
-    static const bool order_env = [] {
-        const char* v = getenv("SRT_LPT");
-        return !v || atoi(v) != 0;
-    }();
+    const bool order_env = dev_switches().lpt;
     bool record = false;
     const size_t nwg = (size_t)grid.x * grid.y;
     if (order_env && !ctx->order_disabled && nwg >= 2048 && p->sample_count >= 4 && !(p->flags & SRT_RENDER_PREVIEW)) {
@@ -604,11 +637,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             if (ctx->order_gx) (void)hipEventSynchronize(ctx->ev_order);  // (long done) the previous upload read h_wg_order
             // linear buckets between the cheapest and the dearest block, expensive first; the counting sort
             // keeps the spatial order inside a bucket
-            static const int NB = [] {
-                const char* v = getenv("SRT_LPT_BUCKETS");
-                int b = v ? atoi(v) : 128;
-                return b < 2 ? 2 : (b > 4096 ? 4096 : b);
-            }();
+            const int NB = dev_switches().lpt_buckets;
             // a launch whose blocks all cost about the same (5th..95th percentile within 1.5x) keeps the
             // natural order: nothing to gain, and neighbouring blocks stay together
             bool uniform = false;
@@ -658,10 +687,12 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
         launch(srt::pathtrace_kernel<3, true, true, false, false>, srt::pathtrace_kernel<3, true, true, true, false>,
                srt::pathtrace_kernel<3, true, true, false, true>, srt::pathtrace_kernel<3, true, false, false, false>,
                srt::pathtrace_kernel<3, true, false, true, false>, srt::pathtrace_kernel<3, true, false, false, true>);
+#ifdef SRT_DEV  // occupancy variants for A/B timing; never in the shipped library
     else if (use == 1 && in_lds && !multi && !defer)
         hipLaunchKernelGGL((srt::pathtrace_kernel<5, false>), grid, block, lds_bytes, ctx->stream, K);
     else if (use == 3 && in_lds && !multi && !defer)
         hipLaunchKernelGGL((srt::pathtrace_kernel<3, false>), grid, block, lds_bytes, ctx->stream, K);
+#endif
     else
         launch(srt::pathtrace_kernel<4, false, true, false, false>, srt::pathtrace_kernel<4, false, true, true, false>,
                srt::pathtrace_kernel<4, false, true, false, true>, srt::pathtrace_kernel<4, false, false, false, false>,
@@ -685,8 +716,9 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     return SRT_OK;
 }
 
-// Development aid, not part of the public header: pick a kernel tuning variant for A/B
-// timing inside one process.  All variants produce identical bits.
+#ifdef SRT_DEV
+// Development aids (libsrt_pathtrace_dev.so only, not part of the public header): the last pick's raw
+// record, and a kernel tuning variant for A/B timing inside one process.  All variants produce identical bits.
 int srt_debug_last_pick(srt_context* ctx, int* out4) {
     if (!ctx || !out4) return SRT_ERR_INVALID_ARG;
     memcpy(out4, ctx->last_pick, sizeof ctx->last_pick);
@@ -698,6 +730,7 @@ int srt_debug_set_variant(srt_context* ctx, int variant) {
     ctx->variant = variant;
     return SRT_OK;
 }
+#endif  // SRT_DEV
 
 #ifdef SRT_STATS
 int srt_debug_read_stats(unsigned long long* out8) {

@@ -102,109 +102,121 @@ inline void build_mesh_image(const srt_object* objects, size_t count, const std:
     };
     std::vector<Node> nodes;
     nodes.reserve(tris.size() / 2 + 16);
-    struct Rec {
-        // depth-first: the left child of node `me` is me + 1, the right child's index is returned
-        static int build(std::vector<Node>& nodes, std::vector<Tri>& tris, int b, int e, int depth, int& max_depth) {
-            const int me = (int)nodes.size();
-            nodes.push_back(Node());
-            Node nd;
-            float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
-            for (int ax = 0; ax < 3; ++ax) {
-                nd.lo[ax] = INFINITY;
-                nd.hi[ax] = -INFINITY;
-            }
-            for (int k = b; k < e; ++k)
-                for (int ax = 0; ax < 3; ++ax) {
-                    nd.lo[ax] = std::min(nd.lo[ax], tris[k].lo[ax]);
-                    nd.hi[ax] = std::max(nd.hi[ax], tris[k].hi[ax]);
-                    clo[ax] = std::min(clo[ax], tris[k].c[ax]);
-                    chi[ax] = std::max(chi[ax], tris[k].c[ax]);
-                }
-            max_depth = std::max(max_depth, depth);
-            if (e - b <= 4) {
-                nd.a = b;
-                nd.b = e - b;
-            } else {
-                // binned surface-area heuristic (16 bins per axis); falls back to the median of the
-                // longest axis when no split is cheaper (leaves must not exceed 4 triangles)
-                auto area = [](const float* lo, const float* hi) {
-                    double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
-                    return dx < 0 ? 0.0 : 2.0 * (dx * dy + dy * dz + dz * dx);
-                };
-                constexpr int NB = 16;
-                int best_axis = -1, best_bin = -1;
-                double best_cost = 1e300;
-                for (int ax = 0; ax < 3; ++ax) {
-                    const double ext = (double)chi[ax] - clo[ax];
-                    if (!(ext > 0)) continue;
-                    float blo[NB][3], bhi[NB][3];
-                    int bcnt[NB];
-                    for (int q = 0; q < NB; ++q) {
-                        bcnt[q] = 0;
-                        for (int a2 = 0; a2 < 3; ++a2) blo[q][a2] = INFINITY, bhi[q][a2] = -INFINITY;
-                    }
-                    for (int k = b; k < e; ++k) {
-                        int q = (int)(((double)tris[k].c[ax] - clo[ax]) / ext * NB);
-                        q = q < 0 ? 0 : (q >= NB ? NB - 1 : q);
-                        bcnt[q]++;
-                        for (int a2 = 0; a2 < 3; ++a2) {
-                            blo[q][a2] = std::min(blo[q][a2], tris[k].lo[a2]);
-                            bhi[q][a2] = std::max(bhi[q][a2], tris[k].hi[a2]);
-                        }
-                    }
-                    double rarea[NB];
-                    int rcnt[NB];
-                    {
-                        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-                        int c = 0;
-                        for (int q = NB - 1; q >= 1; --q) {
-                            for (int a2 = 0; a2 < 3; ++a2) lo[a2] = std::min(lo[a2], blo[q][a2]), hi[a2] = std::max(hi[a2], bhi[q][a2]);
-                            c += bcnt[q];
-                            rarea[q] = area(lo, hi);
-                            rcnt[q] = c;
-                        }
-                    }
-                    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-                    int c = 0;
-                    for (int q = 0; q < NB - 1; ++q) {  // split between bin q and q + 1
-                        for (int a2 = 0; a2 < 3; ++a2) lo[a2] = std::min(lo[a2], blo[q][a2]), hi[a2] = std::max(hi[a2], bhi[q][a2]);
-                        c += bcnt[q];
-                        if (c == 0 || rcnt[q + 1] == 0) continue;
-                        const double cost = area(lo, hi) * c + rarea[q + 1] * rcnt[q + 1];
-                        if (cost < best_cost) best_cost = cost, best_axis = ax, best_bin = q;
-                    }
-                }
-                int mid;
-                if (best_axis >= 0) {
-                    const int ax = best_axis;
-                    const double ext = (double)chi[ax] - clo[ax], lo0 = clo[ax];
-                    const int bin = best_bin;
-                    auto it = std::stable_partition(tris.begin() + b, tris.begin() + e, [=](const Tri& x) {
-                        int q = (int)(((double)x.c[ax] - lo0) / ext * NB);
-                        q = q < 0 ? 0 : (q >= NB ? NB - 1 : q);
-                        return q <= bin;
-                    });
-                    mid = (int)(it - tris.begin());
-                }
-                if (best_axis < 0 || mid == b || mid == e) {  // degenerate: median of the longest axis
-                    int axis = 0;
-                    if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
-                    if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
-                    mid = (b + e) / 2;
-                    std::nth_element(tris.begin() + b, tris.begin() + mid, tris.begin() + e, [axis](const Tri& x, const Tri& y) {
-                        return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.gid < y.gid);
-                    });
-                }
-                build(nodes, tris, b, mid, depth + 1, max_depth);  // left = me + 1
-                nd.a = build(nodes, tris, mid, e, depth + 1, max_depth);
-                nd.b = 0;
-            }
-            nodes[me] = nd;
-            return me;
-        }
+    // Depth-first with an explicit stack (an adversarial mesh — geometrically spaced centroids — lets the
+    // binned SAH peel one triangle off per level, so recursion depth would be O(triangles)): the left child
+    // of node `me` is me + 1, the right child is numbered when the left subtree is complete.  Beyond
+    // SAH_DEPTH levels only median splits are made, which bounds the depth by SAH_DEPTH + log2(n).
+    constexpr int SAH_DEPTH = 40;
+    struct Frame {
+        int b, e, depth, parent;  // parent >= 0: this is that node's right child
     };
-    out.max_depth = 0;
-    Rec::build(nodes, tris, 0, (int)tris.size(), 1, out.max_depth);
+    std::vector<Frame> stack;
+    stack.push_back(Frame{0, (int)tris.size(), 1, -1});
+    int max_depth = 0;
+    while (!stack.empty()) {
+        const Frame f = stack.back();
+        stack.pop_back();
+        const int b = f.b, e = f.e, depth = f.depth;
+        const int me = (int)nodes.size();
+        if (f.parent >= 0) nodes[(size_t)f.parent].a = me;
+        nodes.push_back(Node());
+        Node nd;
+        float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int ax = 0; ax < 3; ++ax) {
+            nd.lo[ax] = INFINITY;
+            nd.hi[ax] = -INFINITY;
+        }
+        for (int k = b; k < e; ++k)
+            for (int ax = 0; ax < 3; ++ax) {
+                nd.lo[ax] = std::min(nd.lo[ax], tris[k].lo[ax]);
+                nd.hi[ax] = std::max(nd.hi[ax], tris[k].hi[ax]);
+                clo[ax] = std::min(clo[ax], tris[k].c[ax]);
+                chi[ax] = std::max(chi[ax], tris[k].c[ax]);
+            }
+        max_depth = std::max(max_depth, depth);
+        if (e - b <= 4) {
+            nd.a = b;
+            nd.b = e - b;
+            nodes[(size_t)me] = nd;
+            continue;
+        }
+        // binned surface-area heuristic (16 bins per axis); falls back to the median of the
+        // longest axis when no split is cheaper (leaves must not exceed 4 triangles)
+        auto area = [](const float* lo, const float* hi) {
+            double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+            return dx < 0 ? 0.0 : 2.0 * (dx * dy + dy * dz + dz * dx);
+        };
+        constexpr int NB = 16;
+        int best_axis = -1, best_bin = -1;
+        double best_cost = 1e300;
+        for (int ax = 0; ax < 3 && depth <= SAH_DEPTH; ++ax) {
+            const double ext = (double)chi[ax] - clo[ax];
+            if (!(ext > 0)) continue;
+            float blo[NB][3], bhi[NB][3];
+            int bcnt[NB];
+            for (int q = 0; q < NB; ++q) {
+                bcnt[q] = 0;
+                for (int a2 = 0; a2 < 3; ++a2) blo[q][a2] = INFINITY, bhi[q][a2] = -INFINITY;
+            }
+            for (int k = b; k < e; ++k) {
+                int q = (int)(((double)tris[k].c[ax] - clo[ax]) / ext * NB);
+                q = q < 0 ? 0 : (q >= NB ? NB - 1 : q);
+                bcnt[q]++;
+                for (int a2 = 0; a2 < 3; ++a2) {
+                    blo[q][a2] = std::min(blo[q][a2], tris[k].lo[a2]);
+                    bhi[q][a2] = std::max(bhi[q][a2], tris[k].hi[a2]);
+                }
+            }
+            double rarea[NB];
+            int rcnt[NB];
+            {
+                float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                int c = 0;
+                for (int q = NB - 1; q >= 1; --q) {
+                    for (int a2 = 0; a2 < 3; ++a2) lo[a2] = std::min(lo[a2], blo[q][a2]), hi[a2] = std::max(hi[a2], bhi[q][a2]);
+                    c += bcnt[q];
+                    rarea[q] = area(lo, hi);
+                    rcnt[q] = c;
+                }
+            }
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            int c = 0;
+            for (int q = 0; q < NB - 1; ++q) {  // split between bin q and q + 1
+                for (int a2 = 0; a2 < 3; ++a2) lo[a2] = std::min(lo[a2], blo[q][a2]), hi[a2] = std::max(hi[a2], bhi[q][a2]);
+                c += bcnt[q];
+                if (c == 0 || rcnt[q + 1] == 0) continue;
+                const double cost = area(lo, hi) * c + rarea[q + 1] * rcnt[q + 1];
+                if (cost < best_cost) best_cost = cost, best_axis = ax, best_bin = q;
+            }
+        }
+        int mid = b;
+        if (best_axis >= 0) {
+            const int ax = best_axis;
+            const double ext = (double)chi[ax] - clo[ax], lo0 = clo[ax];
+            const int bin = best_bin;
+            auto it = std::stable_partition(tris.begin() + b, tris.begin() + e, [=](const Tri& x) {
+                int q = (int)(((double)x.c[ax] - lo0) / ext * NB);
+                q = q < 0 ? 0 : (q >= NB ? NB - 1 : q);
+                return q <= bin;
+            });
+            mid = (int)(it - tris.begin());
+        }
+        if (best_axis < 0 || mid == b || mid == e) {  // degenerate (or very deep): median of the longest axis
+            int axis = 0;
+            if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
+            if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
+            mid = (b + e) / 2;
+            std::nth_element(tris.begin() + b, tris.begin() + mid, tris.begin() + e, [axis](const Tri& x, const Tri& y) {
+                return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.gid < y.gid);
+            });
+        }
+        nd.a = -1;  // set when the right child is numbered
+        nd.b = 0;
+        nodes[(size_t)me] = nd;
+        stack.push_back(Frame{mid, e, depth + 1, me});  // right: after the whole left subtree
+        stack.push_back(Frame{b, mid, depth + 1, -1});  // left = me + 1
+    }
+    out.max_depth = max_depth;
 
     // second pass: collapse the binary tree into 8-wide nodes.  A wide node starts with the two
     // children of a binary inner node and keeps replacing its largest (surface area) inner child

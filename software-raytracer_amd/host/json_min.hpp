@@ -33,8 +33,14 @@ class JsonError : public std::runtime_error {
 // ---- Grisu2 (Loitsch, PLDI 2010): shortest-or-nearly-shortest digits of a double --------
 // The reference writes scenes with nlohmann/json 3.11.2, whose number writer is Grisu2 with
 // alpha = -60, gamma = -32 and cached powers 10^k, k = -300 + 8j.  To reproduce its files byte
-// for byte we need the same digit CHOICE where several 17-digit strings round-trip, so the
-// algorithm is implemented here from the paper (not a correctly-rounding printer).
+// for byte we need the same digit CHOICE where several 17-digit strings round-trip — a correctly
+// rounding printer would differ — so this block is a condensed RE-EXPRESSION of that library's
+// `dtoa_impl` (Raytracer/json.hpp:16865-17588, itself Loitsch's Grisu2): the same DiyFp multiply
+// (32-bit limbs p0..p3), the same k-from-exponent estimate (e * 78913 >> 18), boundary computation,
+// digit generation and grisu2_round condition, because byte identity forces those choices.  It is not
+// an independent design.  What is this project's own: the cached-power table is generated with big-
+// integer arithmetic by host/tools/gen_grisu_table.py (grisu_powers.inc), and the output formatting
+// below.  Differentially tested against the real json.hpp (tests/test_json_vs_reference.py).
 namespace grisu {
 
 struct DiyFp {

@@ -21,6 +21,7 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--mesh", type=int, default=0)
 a = ap.parse_args()
 srt = importlib.import_module("software-raytracer_amd")
+srt.capi.use_dev_library()
 L = srt.load_library()
 L.srt_debug_set_variant.argtypes = [C.c_void_p, C.c_int]
 path = os.path.join(ROOT, "software-raytracer_amd", "scenes", a.scene + ".json")

@@ -58,5 +58,24 @@ int main() {
             for (int k = 0; k < mi.n_tris; ++k) if (seen[(size_t)k] != 1) { std::printf("triangle %d seen %d times (it %d)\n", k, seen[(size_t)k], it); return 1; }
         }
     }
+    {  // adversarial for a binned SAH: geometrically spaced centroids peel one triangle off per level.  The
+       // builder must neither recurse once per triangle nor produce a tree deeper than its median-split bound.
+        srt::HostMesh m;
+        const int nt = 60000;
+        double x = 1e-30;
+        for (int k = 0; k < nt; ++k) {
+            x *= 1.0012;
+            const float f = (float)x;
+            const float v[9] = {f, 0, 0, f * 1.0001f, f * 1e-3f, 0, f, 0, f * 1e-3f};
+            for (float q : v) m.vertices.push_back(q);
+            m.indices.push_back(3 * k), m.indices.push_back(3 * k + 1), m.indices.push_back(3 * k + 2);
+        }
+        srt_object o;
+        memset(&o, 0, sizeof o);
+        o.type = SRT_OBJ_MESH;
+        srt::MeshImage mi;
+        srt::build_mesh_image(&o, 1, std::vector<srt::HostMesh>{m}, 0, mi);
+        if (mi.n_tris != nt || mi.max_depth > 40 + 17) { std::printf("adversarial mesh: %d tris depth %d\n", mi.n_tris, mi.max_depth); return 1; }
+    }
     std::printf("ok nodes %zu vec4 %zu\n", nodes, vec4);
 }

@@ -66,3 +66,14 @@ def test_product_never_touches_the_oracle():
                 assert "srt_oracle" not in text and "libsrt_oracle" not in text, os.path.join(dirpath, f)
     for f in ("include/srt_pathtrace.h", "include/srt_defs.h"):
         assert "srt_oracle" not in open(os.path.join(ROOT, f)).read()
+
+
+def test_shipped_library_has_no_development_hooks(srt):
+    """The shipped ABI is exactly the header: no srt_debug_* entry points and no environment switches
+    (those live in libsrt_pathtrace_dev.so, built with -DSRT_DEV by the development tools only)."""
+    import subprocess
+
+    syms = subprocess.run(["nm", "-D", srt.lib_path()], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r" T (srt_[a-z_0-9]+)", syms)))
+    assert exported == sorted(srt.capi.EXPORTS), exported
+    assert not re.search(r" U (secure_)?getenv", syms), "the shipped library reads the environment"

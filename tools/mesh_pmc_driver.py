@@ -2,6 +2,7 @@ import ctypes as C, importlib, json, os, sys, tempfile
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT)
 srt = importlib.import_module("software-raytracer_amd")
+srt.capi.use_dev_library()
 L = srt.load_library()
 L.srt_debug_set_variant.argtypes = [C.c_void_p, C.c_int]
 path = os.path.join(ROOT, "software-raytracer_amd", "scenes", "Scene1.json")
