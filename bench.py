@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — path-samples/s of the MI355X path-trace hot path (BASELINE.json metric).
 
-A "step" = one pass of the hot path over one batch: ONE srt_render launch that traces
-`spp` samples for every pixel of the frame (accumulator in registers, one framebuffer +
-accumulator store per pixel).
+A "step" = one pass of the hot path over one batch: ONE srt_render call that traces `spp` samples
+for every pixel of this rank's rows (accumulator in registers or, for sample-chunked launches, one
+streaming fold; one framebuffer + accumulator store per pixel), plus — for N > 1 — the one gather.
 
-N = 1 workload = BASELINE.json configs[1]: Scenes/Scene1.json, 1920x1080, 32 spp,
-8 bounces, camera at origin, FOV 55, seed 0, inputs resident in HBM.
-N > 1: the same frame, row-striped over the ranks in memory-row space with
-32*N spp (per-GPU path-samples fixed -> weak scaling), joined by ONE gather to rank 0
-over RCCL (software-raytracer_amd/stripes.py).  Launched by the driver as
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Workloads (BASELINE.json `configs`, 1-based like SURVEY §8):
+  N = 1 (default)      config 2: Scenes/Scene1.json, 1920x1080, 32 spp, 8 bounces, camera at origin, FOV 55.
+  N > 1 (the driver)   config 3's frame and scene, row-striped in EQUAL memory-row bands, 64*N spp
+                       (per-GPU path-samples fixed for N >= 2 -> "weak"; N = 8 is exactly config 3:
+                       512 spp), joined by ONE dist.gather to rank 0 over RCCL.
+  --config C           any of configs 2..5 in its stated form (4 and 5 use the 99,904-triangle ball).
+  --rank k/N           with --config: render rank k's share of an N-rank run (equal stripe, the
+                       config's full spp) on ONE GPU — how configs 3 and 5 are exercised without an
+                       8-GPU node.
 
-Prints ONE JSON line on rank 0.  Extra objects:
-  roofline       HBM view the metric asks for: algorithmic bytes/launch ÷ kernel time vs 8 TB/s
-  roofline_valu  the bound that actually limits this kernel (fp32 VALU, no FMA credit)
-  cpu_baseline   the oracle (CPU port of the reference loop) on this box's host cores, on a
-                 bounded sample of the same workload; also used to assert parity in-run.
+Prints ONE JSON line on rank 0 and exits non-zero if an in-run parity check failed.  Extra objects:
+  roofline       the bound that limits the kernel: fp32 VALU issue without FMA credit.
+                 `achieved` = algorithmic lane-ops per launch / kernel time.  For analytic scenes the
+                 lane-ops are the brute-force-equivalent count of the §8d formula (the kernel culls, so
+                 this is an algorithmic-throughput fraction); for mesh scenes they are COUNTED (BVH node
+                 and triangle tests per ray, profiles/mesh_counts.json).  `measured_valu_issue_frac` is
+                 the pipe utilisation from rocprofv3 counters (profiles/counters.json), `traffic` the
+                 HBM bytes per launch from the same file.
+  roofline_hbm   the HBM view the metric's wording asks for (compulsory bytes / kernel time vs 8 TB/s).
+  cpu_baseline   the oracle (CPU port of the reference loop) on this box's host cores, on a bounded
+                 sample of the same workload; also used to assert parity in-run.
 """
 import argparse
 import ctypes as C
@@ -29,10 +38,19 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WIDTH, HEIGHT, SPP, BOUNCES, SEED, FOV = 1920, 1080, 32, 8, 0, 55
-SCENE = "Scene1"
+SEED, FOV = 0, 55
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 128 * 2.4e9      # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz, no FMA credit
+NODE_OPS, TRI_OPS = 240, 40                # lane-ops per BVH node item (8 child boxes) / triangle test
+
+# BASELINE.json configs, 1-based.  mesh = tessellation of Scene1's big ball (224 -> 99,904 triangles)
+CONFIGS = {
+    1: dict(scene="Scene1", mesh=0, width=256, height=256, spp=1, bounces=4, ranks=1),
+    2: dict(scene="Scene1", mesh=0, width=1920, height=1080, spp=32, bounces=8, ranks=1),
+    3: dict(scene="Scene1", mesh=0, width=1920, height=1080, spp=512, bounces=8, ranks=8),
+    4: dict(scene="Scene1", mesh=224, width=1920, height=1080, spp=64, bounces=8, ranks=1),
+    5: dict(scene="Scene1", mesh=224, width=3840, height=2160, spp=1024, bounces=16, ranks=8),
+}
 
 
 def algorithmic_bytes(width, rows, n_objects, resume):
@@ -42,9 +60,15 @@ def algorithmic_bytes(width, rows, n_objects, resume):
     return px * (4 + 16 + (16 if resume else 0)) + n_objects * 64
 
 
-def algorithmic_laneops_per_sample(rbar, n_sph, n_box):
-    """F = R*(24*N_sph + 35*N_box) + 60*R + 30 fp32 lane-ops per path-sample."""
-    return rbar * (24 * n_sph + 35 * n_box) + 60 * rbar + 30
+def algorithmic_laneops_per_sample(rbar, n_sph, n_box, node_items=0.0, tri_tests=0.0):
+    """F = R*(24*N_sph + 35*N_box) + 60*R + 30 fp32 lane-ops per path-sample, plus — for
+    mesh scenes — the COUNTED BVH work per sample (node items x 240 + triangle tests x 40)."""
+    return rbar * (24 * n_sph + 35 * n_box) + 60 * rbar + 30 + node_items * NODE_OPS + tri_tests * TRI_OPS
+
+
+def workload_key(scene, mesh, width, height, rows, spp, bounces):
+    """Key under which profiles/counters.json and profiles/mesh_counts.json file a workload."""
+    return "%s%s %dx%d rows%d-%d spp%d b%d" % (scene, "+mesh%d" % mesh if mesh else "", width, height, rows[0], rows[1], spp, bounces)
 
 
 def host_cpu_share():
@@ -59,24 +83,49 @@ def host_cpu_share():
     return n
 
 
+def scene_file_for(scene, mesh):
+    """Path of the scene JSON; mesh > 0 writes a temp copy with Scene1's big ball (object 64) replaced
+    by an N x N lat-long tessellation (the EXTENSION workload of configs 4-5)."""
+    path = os.path.join(ROOT, "software-raytracer_amd", "scenes", scene + ".json")
+    if not mesh:
+        return path
+    import tempfile
+
+    sj = json.load(open(path))
+    sj["SceneObjects"][64]["Renderer"] = {"Type": "Mesh", "Primitive": "UVSphere", "Radius": 1.0, "Stacks": mesh, "Slices": mesh}
+    tmp = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
+    json.dump(sj, tmp)
+    tmp.close()
+    return tmp.name
+
+
+def load_json(path):
+    try:
+        return json.load(open(path))
+    except (OSError, ValueError):
+        return {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scene", default=SCENE)
-    ap.add_argument("--width", type=int, default=WIDTH)
-    ap.add_argument("--height", type=int, default=HEIGHT)
-    ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel per GPU-share (x N for N GPUs)")
-    ap.add_argument("--bounces", type=int, default=BOUNCES)
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="BASELINE config in its stated form (default: 2 at N=1)")
+    ap.add_argument("--rank", default="", metavar="k/N", help="with --config on ONE GPU: render rank k's equal stripe of an N-rank run")
+    ap.add_argument("--scene", default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None, help="samples per pixel of the launch (N > 1 without --config: per GPU-share, x N)")
+    ap.add_argument("--bounces", type=int, default=None)
+    ap.add_argument("--mesh", type=int, default=None, metavar="N", help="EXTENSION: replace Scene1's big ball by an N x N tessellation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the bounded CPU sample (16 spp at 1080p = about 20 s of CPU work)")
-    ap.add_argument("--balance", default="cost", choices=["cost", "equal"], help="row-stripe split for N>1")
-    ap.add_argument("--gather", default="p2p", choices=["p2p", "padded"],
-                    help="how cost-balanced (unequal) bands are joined: one grouped isend/irecv in place, or one padded dist.gather")
-    ap.add_argument("--mesh", type=int, default=0, metavar="N",
-                    help="EXTENSION workload (BASELINE configs[3]): replace Scene1's big ball by an N x N lat-long "
-                         "tessellation (224 -> 99,904 triangles); implies --no-cpu-baseline")
+    ap.add_argument("--balance", default="equal", choices=["equal", "cost"],
+                    help="row-stripe split for N > 1: equal bands + one dist.gather (north_star), or cost-balanced bands "
+                         "(opt-in: a probe + one calibration launch before the timed region, reported in the JSON)")
+    ap.add_argument("--gather", default="padded", choices=["padded", "p2p"],
+                    help="cost-balanced (unequal) bands only: one dist.gather of bands padded to the tallest, or one grouped isend/irecv")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -86,6 +135,25 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
+
+    # ---- workload ----------------------------------------------------------------------
+    cfg_id = args.config or (2 if world == 1 else 3)
+    cfg = dict(CONFIGS[cfg_id])
+    if not args.config and world > 1:
+        cfg["spp"] = 64 * world  # per-GPU path-samples fixed; 512 spp = config 3 at N = 8
+    explicit_spp = args.spp is not None
+    for key in ("scene", "width", "height", "spp", "bounces", "mesh"):
+        if getattr(args, key) is not None:
+            cfg[key] = getattr(args, key)
+    if explicit_spp and world > 1 and not args.config:
+        cfg["spp"] = args.spp * world
+    W, H, spp, bounces = cfg["width"], cfg["height"], cfg["spp"], cfg["bounces"]
+    share = None
+    if args.rank:
+        k, n = (int(v) for v in args.rank.split("/"))
+        if world != 1 or not (0 <= k < n):
+            sys.exit("--rank k/N emulates one rank of N on ONE GPU (0 <= k < N)")
+        share = (k, n)
 
     import torch
     import torch.distributed as dist
@@ -110,20 +178,7 @@ def main():
     srt = importlib.import_module("software-raytracer_amd")
     stripes = importlib.import_module("software-raytracer_amd.stripes")
 
-    W, H = args.width, args.height
-    spp = args.spp * world
-    scene_file = os.path.join(ROOT, "software-raytracer_amd", "scenes", args.scene + ".json")
-    if args.mesh:
-        import tempfile
-
-        sj = json.load(open(scene_file))
-        sj["SceneObjects"][64]["Renderer"] = {"Type": "Mesh", "Primitive": "UVSphere", "Radius": 1.0, "Stacks": args.mesh, "Slices": args.mesh}
-        tmp = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
-        json.dump(sj, tmp)
-        tmp.close()
-        scene_file = tmp.name
-        args.no_cpu_baseline = True
-    scene = srt.host.Scene(scene_file)
+    scene = srt.host.Scene(scene_file_for(cfg["scene"], cfg["mesh"]))
     if scene.error:
         sys.exit("scene: " + scene.error)
     objs, n_obj = scene.objects_copy()
@@ -132,10 +187,14 @@ def main():
     n_sph = sum(1 for i in range(n_obj) if objs[i].type == srt.capi.OBJ_SPHERE)
     n_box = sum(1 for i in range(n_obj) if objs[i].type == srt.capi.OBJ_BOX)
 
-    pt = srt.PathTracer(W, H, device=local_rank)
-    pt.set_meshes(meshes, n_mesh)
-    pt.set_scene(objs, n_obj)
-    pt.set_camera(srt.default_camera(FOV))
+    def new_tracer():
+        t = srt.PathTracer(W, H, device=local_rank)
+        t.set_meshes(meshes, n_mesh)
+        t.set_scene(objs, n_obj)
+        t.set_camera(srt.default_camera(FOV))
+        return t
+
+    pt = new_tracer()
     # render straight into a torch tensor so the gather needs no staging copy
     frame = torch.zeros((H, W), dtype=torch.int32, device=dev)
     pt.bind_output(d_framebuffer=frame.data_ptr())
@@ -146,49 +205,48 @@ def main():
     pt.set_stream(stream.cuda_stream)
 
     # ---- row stripes -----------------------------------------------------------------
-    if world > 1 and args.balance == "cost":
-        # per-row cost probe: rays per memory row from a 1-spp pass (deterministic, same on all ranks)
+    calibration = None
+    if share:
+        bands = stripes.partition_rows(H, share[1])
+        rb, re = bands[share[0]]
+    elif world > 1 and args.balance == "cost":
+        # opt-in: per-row cost from a 1-spp ray-count probe (deterministic, same on all ranks), refined by ONE
+        # calibration launch at the real sample count; its cost is reported, it is never inside the timed region
+        t_cal = time.perf_counter()
+        launches = 0
         row_cost = []
-        probe = srt.PathTracer(W, H, device=local_rank)
-        probe.set_meshes(meshes, n_mesh)
-        probe.set_scene(objs, n_obj)
-        probe.set_camera(srt.default_camera(FOV))
+        probe = new_tracer()
         band = 8
-        for rb in range(0, H, band):
-            re = min(rb + band, H)
-            probe.render(spp=1, bounces=args.bounces, seed=SEED, rows=(rb, re), count_rays=True)
-            # cost model: secondary rays dominate; +0.05 per pixel of fixed work
+        for r0 in range(0, H, band):
+            r1 = min(r0 + band, H)
+            probe.render(spp=1, bounces=bounces, seed=SEED, rows=(r0, r1), count_rays=True)
             st = probe.stats()
-            c = (st.rays - W * (re - rb)) + 0.05 * W * (re - rb)
-            row_cost += [c / (re - rb)] * (re - rb)
+            launches += 1
+            # cost model: secondary rays dominate; +0.05 per pixel of fixed work
+            c = (st.rays - W * (r1 - r0)) + 0.05 * W * (r1 - r0)
+            row_cost += [c / (r1 - r0)] * (r1 - r0)
         probe.close()
         bands = stripes.partition_rows(H, world, row_cost, align=8)
-        # refine with MEASURED kernel times (untimed set-up, like building an acceleration structure):
-        # each band's row costs are rescaled so that the band's total matches its measured time, then
-        # the rows are re-partitioned.  A few rounds converge; every rank computes the same split.
-        cal_spp = spp  # the real launch: the library picks tiling / sample chunking from rows and spp
-        best_bands, best_max = bands, float("inf")
-        for _ in range(8):
-            a, b = bands[rank]
-            pt.render(spp=cal_spp, bounces=args.bounces, seed=SEED, first_sample=1, reset=True, rows=(a, b))
-            t_loc = torch.tensor([pt.stats().kernel_ms], dtype=torch.float64, device=cdev)
-            t_all = [torch.zeros_like(t_loc) for _ in range(world)]
-            dist.all_gather(t_all, t_loc)
-            times = [float(t.item()) for t in t_all]
-            if max(times) < best_max:  # keep the best MEASURED split (identical decision on every rank)
-                best_bands, best_max = bands, max(times)
-            if max(times) <= 1.02 * (sum(times) / world):
-                break
+        a, b = bands[rank]
+        pt.render(spp=spp, bounces=bounces, seed=SEED, first_sample=1, reset=True, rows=(a, b))
+        launches += 1
+        t_loc = torch.tensor([pt.stats().kernel_ms], dtype=torch.float64, device=cdev)
+        t_all = [torch.zeros_like(t_loc) for _ in range(world)]
+        dist.all_gather(t_all, t_loc)
+        times = [float(t.item()) for t in t_all]
+        if max(times) > 1.02 * (sum(times) / world):  # rescale every band's rows to its measured time, split again
             for k, (x, y) in enumerate(bands):
-                tot = sum(row_cost[x:y]) or 1.0
-                f = times[k] / tot
+                f = times[k] / (sum(row_cost[x:y]) or 1.0)
                 for r in range(x, y):
                     row_cost[r] *= f
             bands = stripes.partition_rows(H, world, row_cost, align=1)
-        bands = best_bands
+        calibration = {"calibration_launches": launches, "calibration_ms": (time.perf_counter() - t_cal) * 1e3}
+        rb, re = bands[rank]
     else:
         bands = stripes.partition_rows(H, world)
-    rb, re = bands[rank]
+        rb, re = bands[rank]
+    equal_bands = len({b - a for a, b in bands}) == 1
+    gather_method = "gather" if equal_bands else args.gather
 
     # one 8-row launch so that code-object loading is not billed to the first step when --warmup is 0
     # (initialisation like srt_create / srt_set_scene, not a step)
@@ -198,57 +256,57 @@ def main():
     host_frame = torch.zeros((H, W), dtype=torch.int32) if rehearsal else None
 
     def step(count_rays=False):
-        pt.render(spp=spp, bounces=args.bounces, seed=SEED, first_sample=1, reset=True, rows=(rb, re), count_rays=count_rays)
-        if rehearsal and world > 1:  # gloo cannot move device memory: stage through the host
+        pt.render(spp=spp, bounces=bounces, seed=SEED, first_sample=1, reset=True, rows=(rb, re), count_rays=count_rays)
+        if world == 1:
+            return
+        if rehearsal:  # gloo cannot move device memory: stage through the host
             stream.synchronize()
             host_frame[rb:re].copy_(frame[rb:re])
-            stripes.gather_bands(host_frame, bands, rank, world, dist, method=args.gather)
+            stripes.gather_bands(host_frame, bands, rank, world, dist, method=gather_method)
         else:
-            stripes.gather_bands(frame, bands, rank, world, dist, method=args.gather)
+            stripes.gather_bands(frame, bands, rank, world, dist, method=gather_method)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    try:
-        for _ in range(max(args.warmup, 1) if world > 1 else args.warmup):
-            step()
-        fence()
-    except RuntimeError as e:  # a backend that rejects the grouped point-to-point form
-        if world > 1 and args.gather == "p2p":
-            args.gather = "padded"
-            if rank == 0:
-                print("bench.py: grouped isend/irecv failed (%s); using the padded gather" % str(e).splitlines()[0], file=sys.stderr)
-            for _ in range(max(args.warmup, 1)):
-                step()
-            fence()
-        else:
-            raise
-    kernel_ms = []
+    # ---- warm-up (W untimed steps).  The first one is the COLD launch of this frame: no block costs have
+    # been recorded yet, the dispatch order is the host-derived one.  Its kernel time is reported next to
+    # the steady-state time (a moving camera sees the cold number every frame).
+    cold_ms = None
+    n_warm = max(args.warmup, 1) if world > 1 else args.warmup
+    for i in range(n_warm):
+        step()
+        if i == 0:
+            cold_ms = float(pt.stats().kernel_ms)  # synchronises; warm-up only
+    fence()
+
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides; HIP events on the launch
+    # stream bracket the same region (kernel time per launch = event time / K at N = 1)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record(stream)
     for _ in range(args.steps):
         step()
+    ev1.record(stream)
     fence()
     dt = time.perf_counter() - t0
+    stream_ms = ev0.elapsed_time(ev1) / args.steps  # per step on the launch stream (kernels + gather enqueue)
+    last_launch_ms = float(pt.stats().kernel_ms)     # the library's own event pair around the LAST timed launch
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    k_ms = stream_ms if world == 1 else last_launch_ms
 
-    # per-launch kernel time from HIP events on the launch stream (one extra, untimed, launch
-    # per sample so the event pair is read without perturbing the timed region)
-    rays = 0
-    for _ in range(min(args.steps, 5)):
-        pt.render(spp=spp, bounces=args.bounces, seed=SEED, first_sample=1, reset=True, rows=(rb, re), count_rays=True)
-        st = pt.stats()
-        kernel_ms.append(st.kernel_ms)
-        rays = st.rays
-    k_ms = sum(kernel_ms) / len(kernel_ms)
+    # rays per sample (deterministic): one extra, untimed launch with the counter on
+    step(count_rays=True)
+    rays = pt.stats().rays
     local_samples = W * (re - rb) * spp
     rbar_local = rays / local_samples
 
-    total_samples = W * H * spp
+    total_samples = (W * (re - rb) if share else W * H) * spp
     value = total_samples * args.steps / dt
 
     if world > 1:
@@ -268,30 +326,40 @@ def main():
             import numpy as np
 
             gathered = (host_frame if rehearsal else frame.cpu()).numpy().view(np.uint32)
-            chk = srt.PathTracer(W, H, device=local_rank)
-            chk.set_meshes(meshes, n_mesh)
-            chk.set_scene(objs, n_obj)
-            chk.set_camera(srt.default_camera(FOV))
-            chk.render(spp=spp, bounces=args.bounces, seed=SEED)
+            chk = new_tracer()
+            chk.render(spp=spp, bounces=bounces, seed=SEED)
             stripe_parity = bool(np.array_equal(chk.framebuffer(), gathered))
             chk.close()
 
     out = None
     if rank == 0:
         rbar = sum(p[1] for p in per_rank) / sum(p[2] for p in per_rank)
+        key = workload_key(cfg["scene"], cfg["mesh"], W, H, (rb, re), spp, bounces)
+        counters = load_json(os.path.join(ROOT, "profiles", "counters.json")).get(key, {}) if world == 1 else {}
+        mesh_counts = load_json(os.path.join(ROOT, "profiles", "mesh_counts.json")).get(key, {}) if n_tri else {}
+        node_items = mesh_counts.get("node_items_per_sample", 0.0)
+        tri_tests = mesh_counts.get("triangle_tests_per_sample", 0.0)
+        f_sample = algorithmic_laneops_per_sample(rbar_local, n_sph, n_box, node_items, tri_tests)
+        achieved_valu = f_sample * local_samples / (k_ms * 1e-3)
         abytes = algorithmic_bytes(W, re - rb, n_obj, resume=False)
+        if counters.get("chunked"):  # sample-chunked launch: + 16 B written and 16 B read per traced sample (the fold's stream)
+            abytes += int(counters["traced_samples_per_launch"]) * 32
         achieved_gbs = abytes / (k_ms * 1e-3) / 1e9
-        lane_ops = algorithmic_laneops_per_sample(rbar_local, n_sph, n_box) * local_samples
-        achieved_valu = lane_ops / (k_ms * 1e-3)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and world == 1:
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == "%s %dx%d spp%d b%d" % (args.scene, W, H, spp, args.bounces):
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        if n_tri and not mesh_counts:
+            kind = "UNCOUNTED: no profiles/mesh_counts.json entry for this workload; the BVH work is missing from `achieved`"
+        elif n_tri:
+            kind = "counted: analytic part by the SURVEY §8d formula + BVH node items x %d + triangle tests x %d (profiles/mesh_counts.json)" % (NODE_OPS, TRI_OPS)
+        else:
+            kind = "brute-force-equivalent lane-ops of the SURVEY §8d formula (the kernel culls: algorithmic throughput, not pipe utilisation)"
+        measured_issue = None
+        if counters.get("SQ_INSTS_VALU"):
+            measured_issue = counters["SQ_INSTS_VALU"] * 64 / (k_ms * 1e-3) / VALU_PEAK_LANEOPS
+        custom = any(getattr(args, k) is not None for k in ("scene", "width", "height", "spp", "bounces", "mesh"))
+        what = "custom workload (config %d with overrides)" % cfg_id if custom else "config %d" % cfg_id
+        if world > 1 and not args.config and not custom:
+            what = "config 3's frame at 64 spp per GPU-share" + (" = config 3" if world == 8 else "")
+        if share:
+            what += ", rank %d of %d's share on one GPU (memory rows %d-%d)" % (share[0], share[1], rb, re)
         out = {
             "metric": "path-samples/sec at 1920x1080x8-bounce; achieved HBM GB/s vs peak",
             "value": value,
@@ -304,38 +372,56 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (shipped %s.json scene, counter-based RNG seed 0)" % args.scene,
+            "data": "synthetic (shipped %s.json scene%s, counter-based RNG seed 0)" %
+                    (cfg["scene"], ", big ball as a %d-triangle mesh" % n_tri if n_tri else ""),
             "config": {
-                "workload": "%s.json %dx%d, %d spp (%d per GPU-share), %d bounces, FOV %d, camera at origin" %
-                            (args.scene, W, H, spp, args.spp, args.bounces, FOV),
+                "workload": "BASELINE %s: %s.json %dx%d, %d spp, %d bounces, FOV %d, camera at origin" %
+                            (what, cfg["scene"], W, H, spp, bounces, FOV),
+                "workload_key": key,
                 "objects": {"spheres": n_sph, "boxes": n_box, "mesh_triangles": n_tri},
-                "partition": "single frame" if world == 1 else "row stripes in memory-row space, %s split, one RCCL gather (%s)" % (args.balance, args.gather),
-                "bands": bands,
+                "partition": "single frame" if world == 1 and not share else
+                             "row stripes in memory-row space, %s bands, one %s" % (
+                                 args.balance if not share else "equal",
+                                 "dist.gather over RCCL" if gather_method == "gather" else "RCCL gather (%s)" % gather_method),
+                "bands": bands if not share else [[rb, re]],
                 "rays_per_sample": rbar,
             },
             "roofline": {
+                "bound": "valu",
+                "achieved": achieved_valu / 1e12,
+                "peak": VALU_PEAK_LANEOPS / 1e12,
+                "unit": "TFLOP/s",
+                "frac": achieved_valu / VALU_PEAK_LANEOPS,
+                "traffic": counters.get("hbm_bytes_per_launch"),
+                "kernel": "srt::pathtrace_kernel" + (" + srt::fold_kernel" if counters.get("chunked") else ""),
+                "kernel_ms": k_ms,
+                "kernel_ms_source": "HIP events on the launch stream around the %d timed steps / %d" % (args.steps, args.steps)
+                                    if world == 1 else "the library's event pair around the last timed launch",
+                "kernel_ms_last_timed_launch": last_launch_ms,
+                "kernel_ms_cold_first_launch": cold_ms,
+                "peak_note": "fp32 VALU without FMA credit: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (contraction is forbidden by the bit-exactness contract)",
+                "achieved_kind": kind,
+                "algorithmic_laneops_per_sample": f_sample,
+                "rays_per_sample": rbar_local,
+                "measured_valu_issue_frac": measured_issue,
+                "measured_source": counters.get("source"),
+            },
+            "roofline_hbm": {
                 "bound": "hbm",
                 "achieved": achieved_gbs,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "kernel": "srt::pathtrace_kernel",
-                "kernel_ms": k_ms,
+                "traffic": counters.get("hbm_bytes_per_launch"),
                 "algorithmic_bytes_per_launch": abytes,
-                "note": "compulsory bytes only (20 B/pixel + scene); the kernel is VALU-bound, see roofline_valu",
+                "note": "compulsory bytes only (20 B/pixel + scene%s); not the limiting resource" %
+                        (" + 32 B per traced sample of the chunked launch's sample buffer" if counters.get("chunked") else ""),
             },
-            "roofline_valu": {
-                "bound": "valu_fp32_no_fma",
-                "achieved": achieved_valu / 1e12,
-                "peak": VALU_PEAK_LANEOPS / 1e12,
-                "unit": "T lane-op/s",
-                "frac": achieved_valu / VALU_PEAK_LANEOPS,
-                "algorithmic_laneops_per_sample": algorithmic_laneops_per_sample(rbar_local, n_sph, n_box),
-                "rays_per_sample": rbar_local,
-            },
-            "per_rank": [{"kernel_ms": p[0], "rays_per_sample": p[1] / p[2], "rows": list(bands[i])} for i, p in enumerate(per_rank)],
+            "per_rank": [{"kernel_ms": p[0], "rays_per_sample": p[1] / p[2], "rows": list(bands[i] if not share else (rb, re))}
+                         for i, p in enumerate(per_rank)],
         }
+        if calibration:
+            out["config"].update(calibration)
         if world > 1:
             out["stripe_parity_vs_single_device"] = stripe_parity
             if stripe_parity is False:
@@ -351,22 +437,40 @@ def main():
         import srt_oracle_py as O
 
         cores = host_cpu_share()
-        cspp = args.cpu_spp
         oarr = C.cast(objs, C.POINTER(O.Object))
+        omesh = (C.cast(meshes, C.POINTER(O.Mesh)), n_mesh) if n_mesh else None
+        if n_tri:
+            # the CPU port scans every triangle for every ray (~10^5 x the work of an analytic ray): the bounded
+            # sample is a 32 x 16 pixel window over the mesh, inside this rank's rows, at the config's bounces
+            cspp = min(args.cpu_spp, 4)
+            cy = min(max(H // 2, (H - re) + 8), (H - rb) - 8)  # scene row nearest the image centre inside the band
+            mr = H - 1 - cy
+            rows_w, cols_w = (max(rb, mr - 8), min(re, mr + 8)), (W // 2 - 16, W // 2 + 16)
+        else:
+            cspp = args.cpu_spp
+            rows_w, cols_w = (rb, re), None
         t1 = time.perf_counter()
         ofb, oacc, orays = O.render(oarr, n_obj, O.default_environment(), O.default_camera(FOV), W, H, spp=cspp,
-                                    bounces=args.bounces, seed=SEED, pow_mode=O.POW_SHARED, threads=cores)
+                                    bounces=bounces, seed=SEED, pow_mode=O.POW_SHARED, threads=cores, rows=rows_w, cols=cols_w, meshes=omesh)
         cpu_dt = time.perf_counter() - t1
-        # same sample on the GPU: frame hash must match before any speed is reported
+        cw = (cols_w[1] - cols_w[0]) if cols_w else W
+        cpu_samples = cw * (rows_w[1] - rows_w[0]) * cspp
+        # same sample on the GPU: the frames must match before any speed is reported
         pt.bind_output()  # own buffers
-        pt.render(spp=cspp, bounces=args.bounces, seed=SEED, count_rays=True)
+        pt.render(spp=cspp, bounces=bounces, seed=SEED, rows=(rb, re))
         gfb, gacc = pt.framebuffer(), pt.accumulator()
-        parity = bool(np.array_equal(gfb, ofb) and np.array_equal(gacc.view(np.uint32), oacc.view(np.uint32)))
-        # reference-faithful split (16 column stripes, Raytracer.cpp:330-342), 1 spp
-        t2 = time.perf_counter()
-        O.render(oarr, n_obj, O.default_environment(), O.default_camera(FOV), W, H, spp=1, bounces=args.bounces,
-                 seed=SEED, pow_mode=O.POW_LIBM, threads=16, split=O.SPLIT_REF_COLS)
-        ref_dt = time.perf_counter() - t2
+        cs = slice(*cols_w) if cols_w else slice(None)
+        ys = slice(H - rows_w[1], H - rows_w[0])  # scene rows of the window (accumulator layout)
+        g_win, o_win = gfb[rows_w[0]:rows_w[1], cs], ofb[rows_w[0]:rows_w[1], cs]
+        parity = bool(np.array_equal(g_win, o_win) and np.array_equal(gacc[ys, cs].view(np.uint32), oacc[ys, cs].view(np.uint32)))
+        ref_split = None
+        if not n_tri and not share:
+            # reference-faithful split (16 column stripes, Raytracer.cpp:330-342), 1 spp
+            t2 = time.perf_counter()
+            O.render(oarr, n_obj, O.default_environment(), O.default_camera(FOV), W, H, spp=1, bounces=bounces,
+                     seed=SEED, pow_mode=O.POW_LIBM, threads=16, split=O.SPLIT_REF_COLS)
+            ref_dt = time.perf_counter() - t2
+            ref_split = {"value": W * H / ref_dt, "threads": 16, "spp": 1, "seconds": ref_dt}
         cpu_model = ""
         try:
             for line in open("/proc/cpuinfo"):
@@ -376,27 +480,34 @@ def main():
         except OSError:
             pass
         out["cpu_baseline"] = {
-            "value": W * H * cspp / cpu_dt,
+            "value": cpu_samples / cpu_dt,
             "unit": "path-samples/s",
             "cores": cores,
             "kind": "port",
-            "sample": "same scene/camera/seed at %dx%d, %d spp, %d bounces, rows interleaved over %d threads (%.2f s)" %
-                      (W, H, cspp, args.bounces, cores, cpu_dt),
+            "sample": "same scene/camera/seed, %s of the %dx%d frame, %d spp, %d bounces, over %d threads (%.2f s)" %
+                      ("memory rows %d-%d x columns %d-%d" % (rows_w + cols_w) if cols_w else "memory rows %d-%d" % rows_w,
+                       W, H, cspp, bounces, cores, cpu_dt),
             "cpu_model": cpu_model,
-            "reference_split_16_column_stripes": {"value": W * H / ref_dt, "threads": 16, "spp": 1, "seconds": ref_dt},
-            "parity_frame_hash_gpu": O.frame_hash(gfb),
-            "parity_frame_hash_cpu": O.frame_hash(ofb),
+            "reference_split_16_column_stripes": ref_split,
+            "parity_frame_hash_gpu": O.frame_hash(g_win),
+            "parity_frame_hash_cpu": O.frame_hash(o_win),
             "parity_bit_exact": parity,
         }
         if not parity:
             out["value"] = None
             out["error"] = "GPU frame differs from the CPU oracle on the baseline sample; speed not reported"
 
+    failed = False
     if rank == 0:
         print(json.dumps(out))
+        failed = bool(out.get("error"))
     pt.close()
     if world > 1:
+        flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=cdev)
+        dist.broadcast(flag, src=0)
+        failed = bool(flag.item())
         dist.destroy_process_group()
+    sys.exit(1 if failed else 0)
 
 
 if __name__ == "__main__":

@@ -481,6 +481,7 @@ typedef struct worker {
     int x_outer;                    /* reference walk order :235-237 */
     int y_step;                     /* row interleave: thread t takes rows minY, minY + y_step, ... */
     int literal_blocks;             /* run renderArea's own block loop nest (SPLIT_REF_COLS + steps) */
+    int pix_first, pix_step;        /* pix_step > 0: pixels of the window dealt round-robin to the threads */
     uint64_t rays;
 } worker;
 
@@ -559,7 +560,10 @@ static void* worker_main(void* arg) {
         w->rays = c.rays;
         return NULL;
     }
-    if (w->x_outer) {
+    if (w->pix_step > 0) { /* small window of a large frame: one pixel at a time, round-robin */
+        const int ww = w->maxX - w->minX, n = ww * (w->maxY - w->minY);
+        for (int i = w->pix_first; i < n; i += w->pix_step) render_pixel(&c, job, w->minX + i % ww, w->minY + i / ww);
+    } else if (w->x_outer) {
         for (int x = w->minX; x < w->maxX; x++)
             for (int y = w->minY; y < w->maxY; y++) render_pixel(&c, job, x, y);
     } else {
@@ -593,7 +597,27 @@ int srt_oracle_render(srt_oracle_job* job) {
         return SRT_ERR_OOM;
     }
     int n = 0;
-    if (job->split == SRT_ORACLE_SPLIT_REF_COLS) {
+    /* test aid: a column window [col_begin, col_end) of the band (0,0 = all columns).  Only those pixels
+     * are rendered — the frame, the camera and the RNG keys are the full frame's — so a few pixels of a
+     * 4K / 1024-spp frame can be checked against the GPU without rendering the rest on the CPU. */
+    const int window = job->col_end > job->col_begin;
+    if (window && (job->col_begin < 0 || job->col_end > W)) {
+        free(ws);
+        free(th);
+        return SRT_ERR_INVALID_ARG;
+    }
+    if (window) {
+        for (int i = 0; i < T; i++) {
+            ws[n].job = job;
+            ws[n].minX = job->col_begin;
+            ws[n].maxX = job->col_end;
+            ws[n].minY = y0;
+            ws[n].maxY = y1;
+            ws[n].pix_first = i;
+            ws[n].pix_step = T;
+            n++;
+        }
+    } else if (job->split == SRT_ORACLE_SPLIT_REF_COLS) {
         int div = (int)ceil((double)(W / T)) + 1; /* Raytracer.cpp:330 — integer divide first */
         for (int i = 0; i < T; i++) {
             int initialX = div * i, nextX = imin(initialX + div, W); /* :338-340 */

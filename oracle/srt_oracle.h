@@ -47,6 +47,7 @@ typedef struct srt_oracle_job {
     int32_t threads;          /* >= 1 */
     int32_t split;            /* SRT_ORACLE_SPLIT_* */
     uint64_t rays_out;        /* GetClosestObject calls, same counting rule as srt_stats.rays */
+    int32_t col_begin, col_end; /* test aid: render only columns [col_begin, col_end) of the band; 0,0 = all */
 } srt_oracle_job;
 
 /* Render params.sample_count frames of the reference loop for the memory-row band. */

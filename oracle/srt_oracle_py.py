@@ -110,6 +110,8 @@ class Job(C.Structure):
         ("threads", C.c_int32),
         ("split", C.c_int32),
         ("rays_out", C.c_uint64),
+        ("col_begin", C.c_int32),
+        ("col_end", C.c_int32),
     ]
 
 
@@ -278,7 +280,7 @@ def load_scene_json_py(path):
 
 def render(objects, count, env, cam, width, height, *, spp=1, bounces=4, seed=0, first_sample=1,
            reset=True, rows=None, accumulator=None, pow_mode=POW_SHARED, threads=None,
-           split=SPLIT_ROWS, preview=False, steps=1, stripe_width=0, selected=-1, meshes=None):
+           split=SPLIT_ROWS, preview=False, steps=1, stripe_width=0, selected=-1, meshes=None, cols=None):
     """Run the oracle. Returns (framebuffer uint32 [H,W] bottom-up, accumulator float32
     [H,W,4] scene rows, rays)."""
     if threads is None:
@@ -305,6 +307,8 @@ def render(objects, count, env, cam, width, height, *, spp=1, bounces=4, seed=0,
     job.pow_mode = pow_mode
     job.threads = threads
     job.split = split
+    if cols is not None:  # only this column window of the band (the rest of the returned arrays stays zero)
+        job.col_begin, job.col_end = cols
     rc = lib().srt_oracle_render(C.byref(job))
     if rc != 0:
         raise RuntimeError("srt_oracle_render failed: %d" % rc)

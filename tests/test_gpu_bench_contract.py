@@ -28,7 +28,7 @@ def test_single_gpu_line():
     assert d["unit"] == "path-samples/s" and d["dtype"] == "f32" and "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 480 * 270 * 4 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
     rf = d["roofline"]
-    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf
+    assert rf["bound"] in ("hbm", "mfma", "valu") and rf["unit"] in ("GB/s", "TFLOP/s") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"] and cb["sample"]
     assert cb["parity_bit_exact"] is True  # the GPU frame and the oracle's frame of the same sample are identical
