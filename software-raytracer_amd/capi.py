@@ -125,11 +125,11 @@ def use_dev_library(stats=None, rebuild=False):
     counters).  Must be called before the first load_library(); the product and the tests never call it."""
     global _LIB
     assert _lib is None, "use_dev_library() must come before load_library()"
-    dev = os.path.join(_PKG, "libsrt_pathtrace_dev.so")
+    dev = os.path.join(_PKG, "libsrt_pathtrace_dev%s.so" % ("_stats%d" % stats if stats is not None else ""))
     args = ["make", "-C", os.path.join(_PKG, "csrc"), "-s", "dev"]
     if stats is not None:
-        args += ["STATS=%d" % stats, "-B"]
-    elif rebuild:
+        args.append("STATS=%d" % stats)
+    if rebuild:
         args.append("-B")
     subprocess.check_call(args)
     _LIB = dev

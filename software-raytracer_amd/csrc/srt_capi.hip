@@ -36,6 +36,7 @@ struct DevSwitches {
     bool lpt = true;       // SRT_LPT=0: natural dispatch order
     int lpt_buckets = 128; // SRT_LPT_BUCKETS
     bool host_order = true;  // SRT_HOST_ORDER=0: no host-derived initial dispatch order
+    int kernel_flags = 0;    // SRT_KFLAGS: extra KernelParams.flags bits of timing experiments
 };
 #ifdef SRT_DEV
 const DevSwitches& dev_switches() {
@@ -53,6 +54,7 @@ const DevSwitches& dev_switches() {
         int b = geti("SRT_LPT_BUCKETS", 128);
         d.lpt_buckets = b < 2 ? 2 : (b > 4096 ? 4096 : b);
         d.host_order = geti("SRT_HOST_ORDER", 1) != 0;
+        d.kernel_flags = geti("SRT_KFLAGS", 0);
         return d;
     }();
     return sw;
@@ -304,7 +306,7 @@ static int set_scene_impl(srt_context* ctx, const srt_object* objects, size_t co
         // an image that does not fit into LDS next to the per-wave scratch stays in HBM (slower kernel
         // instantiation, same bits); the pick kernel runs one wave, so it is judged separately
         const size_t image_bytes = (size_t)L.total_vec4 * sizeof(float4);
-        const size_t mesh_scratch = has_mesh ? (size_t)srt::WG_MESH_SCRATCH_BYTES : 0;
+        const size_t mesh_scratch = has_mesh ? (size_t)(srt::WG_MESH_SCRATCH_BYTES) : 0;
         ctx->scene_in_lds[v] = image_bytes + srt::WG_SCRATCH_BYTES + mesh_scratch <= (size_t)ctx->lds_limit_bytes;
         ctx->pick_in_lds[v] = image_bytes + srt::WAVE_SCRATCH_BYTES + srt::MESH_WAVE_BYTES <= (size_t)ctx->lds_limit_bytes;
         if (ctx->h_scene[v].size() > ctx->scene_capacity_vec4[v] || !ctx->d_scene[v]) {
@@ -471,12 +473,15 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
     K.max_bounces = p->max_bounces;
     K.seed = p->seed;
     K.flags = p->flags & (SRT_RENDER_RESET | SRT_RENDER_COUNT_RAYS | SRT_RENDER_PREVIEW);
+#ifdef SRT_DEV
+    K.flags |= (uint32_t)dev_switches().kernel_flags;  // SRT_KFLAGS: timing experiments, see the kernel
+#endif
     K.steps = p->steps > 1 ? p->steps : 1;
     K.stripe_width = p->stripe_width > 0 ? p->stripe_width : 0;
     K.selected = p->selected_object;
     use = ctx->variant >= 0 ? ctx->variant : dev_switches().kernel;
     img = (use == 2) ? 1 : 0;  // variant 2: plain brute-force image
-    K.mesh_defer = use >= 100 ? use - 100 : 16;  // variants 100 + n: mesh phases wait for n rays
+    K.mesh_defer = use >= 100 ? use - 100 : 8;  // variants 100 + n: mesh phases wait for n rays
     const srt::SceneLayout& SL = ctx->layout[img];
     K.nu4 = SL.nu4;
     K.nc = SL.nc;
@@ -495,6 +500,7 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
     for (int i = 0; i < 3; ++i) K.mesh_center[i] = ctx->mesh_image.center[i], K.mesh_half[i] = ctx->mesh_image.half[i];
     K.mesh_r1 = (ctx->mesh_image.half[0] + ctx->mesh_image.half[1] + ctx->mesh_image.half[2]) +
                 (fabsf(ctx->mesh_image.center[0]) + fabsf(ctx->mesh_image.center[1]) + fabsf(ctx->mesh_image.center[2]));
+    K.mesh_bs_radius = ctx->mesh_image.bs_radius;
     K.accumulator = ctx->d_acc;
     K.framebuffer = ctx->d_fb;
     K.ray_counter = ctx->d_rays;

@@ -78,6 +78,7 @@ struct KernelParams {
     float mesh_center[3];
     float mesh_half[3];  // root box half extents
     float mesh_r1;       // their sum + |centre|_1
+    float mesh_bs_radius;  // radius of a sphere around mesh_center that contains every triangle
     int32_t mesh_defer;  // path pool: fewest rays that start a mesh phase (closest_hit)
     int32_t tile_h;      // rows of a wave's pixel tile: 8, 4, 2 or 1 (pathtrace_kernel)
     // sample-chunked launches (DEFER instantiation): workgroup z traces samples [z*chunk, (z+1)*chunk) of
@@ -106,7 +107,9 @@ constexpr int RING_DEPTH = 4;  // ring entries per slot when all 64 pixels of th
 constexpr int WAVE_SCRATCH_BYTES = 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4 + 64 * RING_DEPTH * 16;
 constexpr int WG_SCRATCH_BYTES = WAVE_SCRATCH_BYTES * WG_TILES_X * WG_TILES_Y;
 // extra per-wave LDS of the mesh kernel: node LIFO + leaf queue of the cooperative BVH traversal
-constexpr int MESH_QN = 512, MESH_QL = 320;
+// (sized so that three workgroups of the mesh kernel still fit into a CU's 160 KiB next to the Scene1-sized image)
+constexpr int MESH_QN = 448, MESH_QL = 320;
+constexpr float MESH_T_MIN_CULL = 0.0099f;  // just below the smallest valid triangle distance, (float)0.01
 #ifdef SRT_STATS  // development build only (make STATS=1|2): traversal counters read by srt_debug_read_stats
 __device__ unsigned long long g_stats[8];
 #define SRT_STAT(i, v) do { if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
@@ -151,6 +154,7 @@ __device__ __forceinline__ V3 normalized(V3 a) {
     return v3(a.x / length, a.y / length, a.z / length);
 }
 __device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+
 
 struct Lds {
     const float4* v;  // LDS base
@@ -428,7 +432,28 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                 float t1z = ((P.mesh_center[2] - P.mesh_half[2] - pad) - o.z) * inv.z, t2z = ((P.mesh_center[2] + P.mesh_half[2] + pad) - o.z) * inv.z;
                 float tmin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
                 float tmax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
-                go = active && tmin <= tmax * 1.00001f + 1e-6f && tmax >= 0.0f && tmin <= 10001.0f && tmin * 0.9999f - 1e-5f <= best;
+                // a triangle hit is only valid for t >= 0.01 (the Box distance bounds, Object.hpp:226) and lies inside the padded box, so
+                // a box the ray has left before t = 0.0099 holds nothing for it — this is what lets a bounce ray that starts
+                // ON the mesh and points away from it skip the traversal instead of descending to the leaf it came from
+                go = active && tmin <= tmax * 1.00001f + 1e-6f && tmax * 1.00001f + 1e-6f >= MESH_T_MIN_CULL && tmin <= 10001.0f && tmin * 0.9999f - 1e-5f <= best;
+            }
+            // bounding sphere of all triangles (centre C = the root box's, radius R): the ray can only hit something while it
+            // is inside it.  s = (C - o).d, D^2 = |C - o|^2 - s^2; inside for t in [s - q, s + q], q = sqrt(R'^2 - D^2), with
+            // R' = R + 2 * pad (pad bounds every rounding error of the coordinates involved, see above) and the same slack on
+            // D^2 as the cluster bound of srt_scene_image.h.  Needs a unit-length direction; otherwise the box test stands alone.
+            // What this buys: a bounce ray that starts on a round mesh and points away from it leaves the sphere before
+            // t = 0.0099 and skips the traversal, where the box hierarchy would be descended down to the leaf it came from.
+            {
+                const float Lx = P.mesh_center[0] - o.x, Ly = P.mesh_center[1] - o.y, Lz = P.mesh_center[2] - o.z;
+                const float LL = __builtin_fmaf(Lz, Lz, __builtin_fmaf(Ly, Ly, Lx * Lx));
+                const float sd = __builtin_fmaf(Lz, d.z, __builtin_fmaf(Ly, d.y, Lx * d.x));
+                const float dd = __builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x));
+                const float Rp = P.mesh_bs_radius + 2.0f * pad;
+                const float disc = __builtin_fmaf(4e-6f, LL, Rp * Rp) - __builtin_fmaf(-sd, sd, LL);
+                const float q = __builtin_amdgcn_sqrtf(fmaxf(disc, 0.0f)) * 1.00001f;
+                const bool unit = fabsf(dd - 1.0f) <= 1e-6f;
+                const bool inside = disc >= 0.0f && (sd + q) + pad >= MESH_T_MIN_CULL && ((sd - q) - pad) * 0.9999f - 1e-5f <= best;
+                go = go && (inside || !unit);
             }
             // ---- wave-cooperative traversal of the 8-wide BVH.  Rays that come near the mesh put
             // (ray lane, node) items on a LIFO in LDS.  A node round pops items and tests the 8 quantized
@@ -447,6 +472,9 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             // few rays take part, and most phases would be started by two or three stray bounce rays.  So
             // unless at least `defer_min` rays want the mesh — or no lane has anything else to do — the
             // rays are reported back as deferred: the pool parks them and offers them again next round.
+#ifdef SRT_DEV  // timing experiments (results are wrong): 0x100 = no mesh phases at all, 0x200 = no triangle tests
+            if (P.flags & 0x100u) go = false;
+#endif
             unsigned long long pend = __builtin_amdgcn_ballot_w64(go);
             const int n_go = __builtin_popcountll(pend);
             if (n_go < defer_min && n_go != __builtin_popcountll(__builtin_amdgcn_ballot_w64(active))) {
@@ -465,19 +493,38 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                 };
                 auto unkey = [](unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u); };
                 bool overflow = false;
+                auto mbcnt64 = [](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
                 auto push = [&](bool pred, unsigned item, unsigned* q, int& n, int cap) {
                     const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
                     const int cnt = __builtin_popcountll(m);
                     if (n + cnt > cap) {
                         overflow = true;
                     } else {
-                        if (pred) q[n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = item;
+                        if (pred) q[n + mbcnt64(m)] = item;
                         n += cnt;
+                    }
+                };
+                // exclusive wave prefix sum of per-lane counts <= 8 (bit-sliced through ballots; empty slices are skipped)
+                auto prefix_small = [&](int cnt, int& prefix, int& total) {
+                    prefix = 0;
+                    total = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(((cnt >> b) & 1) != 0);
+                        if (bal != 0ull) {
+                            prefix += mbcnt64(bal) << b;
+                            total += __builtin_popcountll(bal) << b;
+                        }
                     }
                 };
                 S.res[lane] = ((unsigned long long)okey(best) << 32) | 0xFFFFFFFFull;  // no triangle yet
                 int batch = 64;
                 bool strict = false;
+#if defined(SRT_STATS) && SRT_STATS == 4  // make dev STATS=4: where a mesh phase spends its wave-cycles (tests/mesh_stats.py)
+                const long long st_t0 = (long long)__builtin_readcyclecounter();
+                long long st_node = 0, st_leaf = 0, st_wait = 0;
+                int st_nr = 0, st_lr = 0;
+#endif
 #ifdef SRT_STATS
                 const int st_cls = n_go <= 2 ? 0 : n_go <= 8 ? 1 : n_go <= 32 ? 2 : 3;
                 int st_rounds = 0;
@@ -489,7 +536,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                 while (pend != 0ull) {
                     // the next (up to `batch`) waiting rays enter at the root
                     const bool mine = (pend >> lane) & 1ull;
-                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pend >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pend, 0u));
+                    const int rank = mbcnt64(pend);
                     const bool sel = mine && rank < batch;
                     const unsigned long long selmask = __builtin_amdgcn_ballot_w64(sel);
                     int nN = 0, nL = 0;
@@ -497,113 +544,208 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                     push(sel, (unsigned)lane << 26, qn, nN, MESH_QN);
                     __builtin_amdgcn_wave_barrier();
                     while (!overflow && (nN > 0 || nL > 0)) {
+                        // ---- one round pops items of ONE queue (serving both in one round was tried: one round trip fewer
+                        // per level, but the two code paths together spill 30 registers and the launch got 45 % slower).
+                        // Nodes first, until 64 leaves wait: a node's 8 children are spread over 8 / 4 / 2 / 1 lanes so that the
+                        // wave stays full however few items wait; a leaf gets four lanes, one triangle each — one memory
+                        // round trip per leaf round instead of one per triangle.
                         const bool node_round = nN > 0 && nL < 64;
-                        // eight lanes per node / four per leaf when few items wait
-                        const bool wide = strict || (node_round ? nN <= 8 : nL <= 16);
-                        const int per = wide ? (node_round ? 8 : 4) : 1;
-                        int& n = node_round ? nN : nL;
-                        int take = n < 64 / per ? n : 64 / per;
-                        if (strict && node_round) take = 1;
-                        if (node_round && !wide) {  // leave room for the expected pushes (about 3 per item)
-                            int room = (MESH_QN - nN) / 3;
-                            const int lroom = (MESH_QL - nL) / 3;
-                            room = room < lroom ? room : lroom;
-                            room = room < 8 ? 8 : room;
-                            take = take < room ? take : room;
+                        const int takeL = node_round ? 0 : (nL < 16 ? nL : 16);
+                        const int lanesN = 64 - 4 * takeL;
+                        int logP = 0, takeN = 0;
+                        if (node_round) {
+                            if (strict) {
+                                logP = 3, takeN = 1;
+                            } else {
+                                logP = nN <= 8 ? 3 : nN <= 16 ? 2 : nN <= 32 ? 1 : 0;
+                                takeN = nN < (64 >> logP) ? nN : (64 >> logP);
+                                // leave room for the expected pushes (about 3 per item)
+                                int room = (MESH_QN - nN) / 3;
+                                const int lroom = (MESH_QL - nL) / 3;
+                                room = room < lroom ? room : lroom;
+                                room = room < 8 ? 8 : room;
+                                takeN = takeN < room ? takeN : room;
+                            }
                         }
-                        n -= take;
+                        nN -= takeN;  // the items [nN, nN + takeN) and [nL, nL + takeL) are popped
+                        nL -= takeL;
 #ifdef SRT_STATS
                         if (SRT_STATS == 1) {
-                            SRT_STAT(node_round ? 2 : 4, 1);
-                            SRT_STAT(node_round ? 3 : 5, take);
+                            SRT_STAT(2, takeN > 0 ? 1 : 0);
+                            SRT_STAT(3, takeN);
+                            SRT_STAT(4, takeL > 0 ? 1 : 0);
+                            SRT_STAT(5, takeL);
                         }
                         st_rounds += 1;
 #endif
-                        const int slot = wide ? (node_round ? lane >> 3 : lane >> 2) : lane;
-                        const bool on = slot < take;
-                        const unsigned item = on ? (node_round ? qn : ql)[n + slot] : 0u;  // item 0 = (lane 0, root / first leaf): valid memory
+#if defined(SRT_STATS) && SRT_STATS == 4
+                        const long long st_r0 = (long long)__builtin_readcyclecounter();
+#endif
+                        const int slotN = lane >> logP, sub = lane & ((1 << logP) - 1);
+                        const int ll = lane - lanesN, subL = ll & 3;
+                        const bool onL = ll >= 0, onN = !onL && slotN < takeN;
+                        const unsigned item = onN ? qn[nN + slotN] : onL ? ql[nL + (ll >> 2)] : 0u;
                         const int src = (int)(item >> 26), code = (int)(item & 0x3FFFFFFu);
+                        // the rows of the item — five of a node or three of a triangle, in the same registers — are requested
+                        // before the ray is fetched, so that the memory round trip overlaps the shuffles
+                        const int lcnt = (code & 3) + 1;  // leaf items: (first triangle) * 4 + (count - 1)
+                        // (every lane loads — idle lanes the root / the first triangle: a load under a lane mask would make the
+                        // compiler wait for it right here, to merge the registers with those of the lanes that do not load)
+                        // (the top levels of the tree need no copy in LDS: they stay in the vector L1, a copy measured no faster)
+                        const float4* rowp = node_round ? P.bvh_nodes + 5 * (size_t)code : P.bvh_tris + 3 * (size_t)((code >> 2) + (subL < lcnt ? subL : 0));
+                        const float4 r0 = rowp[0], r1 = rowp[1], r2 = rowp[2];
+                        float4 r3 = make_float4(0, 0, 0, 0), r4 = r3;
+                        if (node_round) r3 = rowp[3], r4 = rowp[4];
                         const V3 ro = v3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
                         const V3 rd = v3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
                         const float rpad = __shfl(pad, src);
-                        __builtin_amdgcn_wave_barrier();
+#if defined(SRT_STATS) && SRT_STATS == 4
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        st_wait += (long long)__builtin_readcyclecounter() - st_r0;
+#endif
                         if (node_round) {
+                            const float4 h0 = r0, h1 = r1, q0 = r2, q1 = r3, q2 = r4;
                             const float thr = unkey((unsigned)(S.res[src] >> 32));
-                            const float4 n0 = P.bvh_nodes[6 * code], n1 = P.bvh_nodes[6 * code + 1], n2 = P.bvh_nodes[6 * code + 2],
-                                         n3 = P.bvh_nodes[6 * code + 3], n4 = P.bvh_nodes[6 * code + 4], n5 = P.bvh_nodes[6 * code + 5];
+                            // a child is entered only if a triangle inside could still beat the ray's best hit: entry distance
+                            // <= (thr + 1e-5) / 0.9999 (written as an upper bound of it), and <= 10001
+                            const float thr2 = fminf(__builtin_fmaf(fabsf(thr), 2e-4f, thr + 1e-5f), 10001.0f);
                             // slopes clamped to 2^96: an axis the ray (almost) does not move along keeps its
                             // sign-correct, still astronomically large plane distances without inf * 0
                             const float BIG = 0x1p96f;
                             const V3 rinv = v3(fminf(fmaxf(__builtin_amdgcn_rcpf(rd.x), -BIG), BIG), fminf(fmaxf(__builtin_amdgcn_rcpf(rd.y), -BIG), BIG),
                                                fminf(fmaxf(__builtin_amdgcn_rcpf(rd.z), -BIG), BIG));
-                            const unsigned ex = __float_as_uint(n0.w);
+                            const unsigned ex = __float_as_uint(h0.w);
+                            const unsigned innermask = ex >> 24, lw = __float_as_uint(h1.z), leafmask = lw & 255u, counts = lw >> 8;
                             // plane distance = q * (cell * rinv) + ((origin -/+ pad) - ro) * rinv, one FMA per plane
                             const float sx = __uint_as_float((ex & 255u) << 23) * rinv.x, sy = __uint_as_float(((ex >> 8) & 255u) << 23) * rinv.y,
                                         sz = __uint_as_float(((ex >> 16) & 255u) << 23) * rinv.z;
-                            const float lx0 = ((n0.x - rpad) - ro.x) * rinv.x, hx0 = ((n0.x + rpad) - ro.x) * rinv.x;
-                            const float ly0 = ((n0.y - rpad) - ro.y) * rinv.y, hy0 = ((n0.y + rpad) - ro.y) * rinv.y;
-                            const float lz0 = ((n0.z - rpad) - ro.z) * rinv.z, hz0 = ((n0.z + rpad) - ro.z) * rinv.z;
-                            const unsigned tag = (unsigned)src << 26;
-                            auto byte_of = [](float lo4, float hi4, int c) {
-                                const unsigned w = __float_as_uint(c >= 4 ? hi4 : lo4);
-                                return (float)((w >> ((c & 3) * 8)) & 255u);
+                            const float lx0 = ((h0.x - rpad) - ro.x) * rinv.x, hx0 = ((h0.x + rpad) - ro.x) * rinv.x;
+                            const float ly0 = ((h0.y - rpad) - ro.y) * rinv.y, hy0 = ((h0.y + rpad) - ro.y) * rinv.y;
+                            const float lz0 = ((h0.z - rpad) - ro.z) * rinv.z, hz0 = ((h0.z + rpad) - ro.z) * rinv.z;
+                            // the ray's direction picks the entry and the exit plane of every axis once per node (lo <= hi and a
+                            // monotone FMA, so this equals the min / max of the two plane distances); an absent child has an
+                            // inverted box and sits in neither mask
+                            const bool px = rinv.x >= 0.0f, py = rinv.y >= 0.0f, pz = rinv.z >= 0.0f;
+                            const float bnx = px ? lx0 : hx0, bfx = px ? hx0 : lx0, bny = py ? ly0 : hy0, bfy = py ? hy0 : ly0, bnz = pz ? lz0 : hz0,
+                                        bfz = pz ? hz0 : lz0;
+                            // byte planes: children 0..3 in the first word of a plane, 4..7 in the second
+                            const unsigned lox0 = __float_as_uint(q0.x), lox1 = __float_as_uint(q0.y), loy0 = __float_as_uint(q0.z), loy1 = __float_as_uint(q0.w);
+                            const unsigned loz0 = __float_as_uint(q1.x), loz1 = __float_as_uint(q1.y), hix0 = __float_as_uint(q1.z), hix1 = __float_as_uint(q1.w);
+                            const unsigned hiy0 = __float_as_uint(q2.x), hiy1 = __float_as_uint(q2.y), hiz0 = __float_as_uint(q2.z), hiz1 = __float_as_uint(q2.w);
+                            auto byte_f = [](unsigned w, int b) { return (float)((w >> (8 * b)) & 255u); };
+                            // child whose six plane bytes are byte b of the given words: is its (padded) box entered?
+                            auto enters = [&](unsigned nx, unsigned ny, unsigned nz, unsigned fx, unsigned fy, unsigned fz, int b) {
+                                const float tnx = __builtin_fmaf(byte_f(nx, b), sx, bnx), tfx = __builtin_fmaf(byte_f(fx, b), sx, bfx);
+                                const float tny = __builtin_fmaf(byte_f(ny, b), sy, bny), tfy = __builtin_fmaf(byte_f(fy, b), sy, bfy);
+                                const float tnz = __builtin_fmaf(byte_f(nz, b), sz, bnz), tfz = __builtin_fmaf(byte_f(fz, b), sz, bfz);
+                                const float tn = fmaxf(fmaxf(tnx, tny), tnz), tf = fminf(fminf(tfx, tfy), tfz);
+                                // exit distance >= the smallest valid t, folded into the entry side; a NaN entry stays NaN and rejects
+                                const float lo = (MESH_T_MIN_CULL > tn) ? MESH_T_MIN_CULL : tn;
+                                const float hi = fminf(__builtin_fmaf(tf, 1.00001f, 1e-6f), thr2);
+                                return lo <= hi;
                             };
-                            auto child = [&](int c) {
-                                const float t1x = __builtin_fmaf(byte_of(n1.x, n1.y, c), sx, lx0), t2x = __builtin_fmaf(byte_of(n2.z, n2.w, c), sx, hx0);
-                                const float t1y = __builtin_fmaf(byte_of(n1.z, n1.w, c), sy, ly0), t2y = __builtin_fmaf(byte_of(n3.x, n3.y, c), sy, hy0);
-                                const float t1z = __builtin_fmaf(byte_of(n2.x, n2.y, c), sz, lz0), t2z = __builtin_fmaf(byte_of(n3.z, n3.w, c), sz, hz0);
-                                const float tmin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
-                                const float tmax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
-                                const float4 rlo = c >= 4 ? n5 : n4;
-                                const int cc = c & 3;
-                                const int ref = __float_as_int(cc == 0 ? rlo.x : cc == 1 ? rlo.y : cc == 2 ? rlo.z : rlo.w);
-                                // entered only if a triangle inside could still beat the ray's best hit
-                                const bool hit = on & (ref != 0) & (tmin <= tmax * 1.00001f + 1e-6f) & (tmax >= 0.0f) & (tmin <= 10001.0f) &
-                                                 (tmin * 0.9999f - 1e-5f <= thr);
-                                push(hit & (ref > 0), tag | (unsigned)ref, qn, nN, MESH_QN);
-                                push(hit & (ref < 0), tag | (unsigned)(-ref - 1), ql, nL, MESH_QL);
-                            };
-                            if (wide) {
-                                child(lane & 7);
-                            } else {
+                            unsigned mask = 0u;
+                            if (logP == 0) {  // one lane per item: all 8 children
+                                const unsigned nx0 = px ? lox0 : hix0, fx0 = px ? hix0 : lox0, ny0 = py ? loy0 : hiy0, fy0 = py ? hiy0 : loy0, nz0 = pz ? loz0 : hiz0,
+                                               fz0 = pz ? hiz0 : loz0;
+                                const unsigned nx1 = px ? lox1 : hix1, fx1 = px ? hix1 : lox1, ny1 = py ? loy1 : hiy1, fy1 = py ? hiy1 : loy1, nz1 = pz ? loz1 : hiz1,
+                                               fz1 = pz ? hiz1 : loz1;
 #pragma unroll
-                                for (int c = 0; c < 8; ++c) child(c);
+                                for (int b = 0; b < 4; ++b) {
+                                    mask |= enters(nx0, ny0, nz0, fx0, fy0, fz0, b) ? (1u << b) : 0u;
+                                    mask |= enters(nx1, ny1, nz1, fx1, fy1, fz1, b) ? (16u << b) : 0u;
+                                }
+                            } else {  // 2 / 4 / 8 lanes per item: this lane takes 4 / 2 / 1 consecutive children
+                                const int nb = 8 >> logP;                 // children of this lane
+                                const int first = sub * nb;                // its first child
+                                const bool second = first >= 4;            // which word of the planes
+                                const unsigned sh = (unsigned)(first & 3) * 8u;
+                                const unsigned wlx = (second ? lox1 : lox0) >> sh, wly = (second ? loy1 : loy0) >> sh, wlz = (second ? loz1 : loz0) >> sh;
+                                const unsigned whx = (second ? hix1 : hix0) >> sh, why = (second ? hiy1 : hiy0) >> sh, whz = (second ? hiz1 : hiz0) >> sh;
+                                const unsigned nx = px ? wlx : whx, fx = px ? whx : wlx, ny = py ? wly : why, fy = py ? why : wly, nz = pz ? wlz : whz, fz = pz ? whz : wlz;
+                                unsigned m4 = enters(nx, ny, nz, fx, fy, fz, 0) ? 1u : 0u;
+                                if (nb >= 2) {
+                                    m4 |= enters(nx, ny, nz, fx, fy, fz, 1) ? 2u : 0u;
+                                    if (nb == 4) {
+                                        m4 |= enters(nx, ny, nz, fx, fy, fz, 2) ? 4u : 0u;
+                                        m4 |= enters(nx, ny, nz, fx, fy, fz, 3) ? 8u : 0u;
+                                    }
+                                }
+                                mask = m4 << first;
                             }
-                        } else {
-                            const int first = code >> 2, cnt = (code & 3) + 1;
-                            float tb = __builtin_inff();
-                            int gb = 0x7fffffff;
-                            auto triangle = [&](int k) {
-                                const int q = first + (k < cnt ? k : 0);
-                                const float4 a = P.bvh_tris[3 * q], b = P.bvh_tris[3 * q + 1], c = P.bvh_tris[3 * q + 2];
-                                // Moller-Trumbore, binary32, no FMA, fixed order (the oracle's triangle_raytrace)
-                                V3 pv = v3(rd.y * c.z - rd.z * c.y, rd.z * c.x - rd.x * c.z, rd.x * c.y - rd.y * c.x);
-                                float det = (b.x * pv.x + b.y * pv.y) + b.z * pv.z;
-                                float idet = 1.0f / det;
-                                V3 tv = v3(ro.x - a.x, ro.y - a.y, ro.z - a.z);
-                                float u = ((tv.x * pv.x + tv.y * pv.y) + tv.z * pv.z) * idet;
-                                V3 qv = v3(tv.y * b.z - tv.z * b.y, tv.z * b.x - tv.x * b.z, tv.x * b.y - tv.y * b.x);
-                                float vv = ((rd.x * qv.x + rd.y * qv.y) + rd.z * qv.z) * idet;
-                                float t = ((c.x * qv.x + c.y * qv.y) + c.z * qv.z) * idet;
-                                const bool ok = on & (k < cnt) & (fabsf(det) >= 1e-12f) & (u >= 0.0f) & (u <= 1.0f) & (vv >= 0.0f) & (u + vv <= 1.0f) &
-                                                (t >= (float)0.01) & (t <= 10000.0f);
-                                const int gid = __float_as_int(b.w);
-                                // (distance, triangle id) lexicographic minimum.  Written as branch-free boolean
-                                // algebra + selects on purpose: hipcc (ROCm 7.2) lowers the nested short-circuit
-                                // form of such an update into exec-mask code that loses one of the state updates
-                                // for lanes winning through the tie term (seen in the ISA).
-                                const bool win = ok & ((t < tb) | ((t == tb) & (gid < gb)));
-                                tb = win ? t : tb;
-                                gb = win ? gid : gb;
-                            };
-                            if (wide) {
-                                triangle(lane & 3);
-                            } else {
-                                for (int k = 0; k < 4; ++k) triangle(k);
+                            if (!onN) mask = 0u;
+                            const unsigned tag = (unsigned)src << 26;
+                            {  // surviving inner children -> node LIFO
+                                unsigned m = mask & innermask;
+                                int pre, tot;
+                                prefix_small(__builtin_popcount(m), pre, tot);
+                                if (nN + tot > MESH_QN) {
+                                    overflow = true;
+                                } else {
+                                    const unsigned first_inner = __float_as_uint(h1.x);
+                                    int w = nN + pre;
+                                    while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
+                                        if (m != 0u) {
+                                            const unsigned below = (m & (0u - m)) - 1u;  // mask of the children before the lowest survivor
+                                            qn[w++] = tag | (first_inner + (unsigned)__builtin_popcount(innermask & below));
+                                            m &= m - 1u;
+                                        }
+                                    }
+                                    nN += tot;
+                                }
                             }
-                            if (gb != 0x7fffffff) atomicMin(&S.res[src], ((unsigned long long)okey(tb) << 32) | (unsigned)gb);
+                            {  // surviving leaf children -> leaf queue, item = (first triangle) * 4 + (count - 1)
+                                unsigned m = mask & leafmask;
+                                int pre, tot;
+                                prefix_small(__builtin_popcount(m), pre, tot);
+                                if (nL + tot > MESH_QL) {
+                                    overflow = true;
+                                } else if (tot > 0) {
+                                    const unsigned first_tri = __float_as_uint(h1.y);
+                                    int w = nL + pre;  // (over this round's popped items: their reads have long completed)
+                                    while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
+                                        if (m != 0u) {
+                                            const unsigned bit = m & (0u - m), below = bit - 1u;
+                                            const unsigned below2 = bit * bit - 1u;  // the count fields (2 bits each) of the children before
+                                            const unsigned cf = counts & below2;
+                                            const unsigned first = first_tri + (unsigned)__builtin_popcount(leafmask & below) + (unsigned)__builtin_popcount(cf & 0x5555u) +
+                                                                   2u * (unsigned)__builtin_popcount(cf & 0xAAAAu);
+                                            const unsigned c2 = 2u * (unsigned)__builtin_ctz(bit);
+                                            ql[w++] = tag | (first * 4u + ((counts >> c2) & 3u));
+                                            m &= m - 1u;
+                                        }
+                                    }
+                                    nL += tot;
+                                }
+                            }
+                        }
+                        else {
+                            const float4 a = r0, b = r1, c = r2;
+                            // Moller-Trumbore, binary32, no FMA, fixed order (the oracle's triangle_raytrace)
+                            V3 pv = v3(rd.y * c.z - rd.z * c.y, rd.z * c.x - rd.x * c.z, rd.x * c.y - rd.y * c.x);
+                            float det = (b.x * pv.x + b.y * pv.y) + b.z * pv.z;
+                            float idet = 1.0f / det;
+                            V3 tv = v3(ro.x - a.x, ro.y - a.y, ro.z - a.z);
+                            float u = ((tv.x * pv.x + tv.y * pv.y) + tv.z * pv.z) * idet;
+                            V3 qv = v3(tv.y * b.z - tv.z * b.y, tv.z * b.x - tv.x * b.z, tv.x * b.y - tv.y * b.x);
+                            float vv = ((rd.x * qv.x + rd.y * qv.y) + rd.z * qv.z) * idet;
+                            float t = ((c.x * qv.x + c.y * qv.y) + c.z * qv.z) * idet;
+                            bool ok = onL & (subL < lcnt) & (fabsf(det) >= 1e-12f) & (u >= 0.0f) & (u <= 1.0f) & (vv >= 0.0f) & (u + vv <= 1.0f) &
+                                      (t >= (float)0.01) & (t <= 10000.0f);
+#ifdef SRT_DEV
+                            if (P.flags & 0x200u) ok = false;
+#endif
+                            // the merge key is (ordered t || global triangle id): the id order is (list order of the object,
+                            // triangle index), i.e. the tie rule; atomicMin makes the merge order-independent
+                            if (ok) atomicMin(&S.res[src], ((unsigned long long)okey(t) << 32) | (unsigned)__float_as_int(b.w));
                         }
                         __builtin_amdgcn_wave_barrier();
+#if defined(SRT_STATS) && SRT_STATS == 4
+                        {
+                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                            st_node += (long long)__builtin_readcyclecounter() - st_r0, st_nr += 1;
+                        }
+#endif
                     }
                     if (!overflow) {
                         pend &= ~selmask;
@@ -619,6 +761,15 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                     if (SRT_STATS == 1 && overflow) SRT_STAT(6, 1);
 #endif
                 }
+#if defined(SRT_STATS) && SRT_STATS == 4
+                SRT_STAT(0, (long long)__builtin_readcyclecounter() - st_t0);
+                SRT_STAT(1, st_node);
+                SRT_STAT(2, st_leaf);
+                SRT_STAT(3, st_wait);
+                SRT_STAT(4, st_nr);
+                SRT_STAT(5, st_lr);
+                SRT_STAT(6, 1);
+#endif
 #ifdef SRT_STATS
                 if (SRT_STATS == 2) {  // histogram by the number of rays entering the phase: phases / rounds per class
                     SRT_STAT(st_cls, 1);

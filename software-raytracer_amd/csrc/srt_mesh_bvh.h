@@ -6,15 +6,20 @@
 //            (v0.xyz, bits(primitive id p))      p indexes the LDS material table
 //            (e1.xyz, bits(global triangle id))  id = position in (object list order, triangle
 //            (e2.xyz, bits(list index))               index) — restores the tie rule
-//   nodes: 6 float4 (96 B) per 8-WIDE inner node, child boxes quantized to 8 bits on the node's own box:
-//            (origin.xyz, bits(ex | ey<<8 | ez<<16))   cell size per axis = 2^(e-127)
+//   nodes: 5 float4 (80 B) per 8-WIDE inner node, child boxes quantized to 8 bits on the node's own box:
+//            (origin.xyz, bits(ex | ey<<8 | ez<<16 | innermask<<24))   cell size per axis = 2^(e-127)
+//            (bits(first inner child), bits(first leaf triangle), bits(leafmask | counts<<8), 0)
 //            (lo.x[0..3], lo.x[4..7], lo.y[0..3], lo.y[4..7])   one byte per child
 //            (lo.z[0..3], lo.z[4..7], hi.x[0..3], hi.x[4..7])
 //            (hi.y[0..3], hi.y[4..7], hi.z[0..3], hi.z[4..7])
-//            (ref[0..3]) (ref[4..7])
 //          child box = origin + q*cell, lo rounded down / hi up, so it encloses the exact box.
-//          ref > 0: inner node index; ref < 0: leaf, -(1 + first*4 + (count-1)); ref == 0: no child.
-//          Node 0 is the root; a mesh of <= 4 triangles is a root with one leaf child.
+//          Children are IMPLICIT: nodes are numbered breadth-first, so the inner children of a node are
+//          consecutive — child c (bit c of innermask) is node  first_inner + popcount(innermask & ((1<<c)-1));
+//          triangles are stored in the same breadth-first order, so the leaf children of a node are
+//          consecutive too — child c (bit c of leafmask) holds  1 + ((counts >> 2c) & 3)  triangles starting at
+//          first_leaf_triangle + the sum of the counts of the leaf children before it.  A child in neither
+//          mask is absent (its box is inverted).  Node 0 is the root; a mesh of <= 4 triangles is a root
+//          with one leaf child.
 // Build: binary binned surface-area heuristic (16 bins per axis, median fallback), leaves of <= 4
 // triangles, then collapsed to 8 children per node — deterministic.  Bounds are exact (float min/max of the float vertices); the
 // kernel pads them per ray (see closest_hit) so that the box filter is conservative with
@@ -27,6 +32,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <stdexcept>
 #include <vector>
 
 #include "srt_pathtrace.h"
@@ -38,11 +44,14 @@ struct HostMesh {
     std::vector<uint32_t> indices;
 };
 
+constexpr int NODE_VEC4 = 5;  // float4 per node (80 B)
+
 struct MeshImage {
     std::vector<float4> tris, nodes;
     std::vector<int32_t> gidpos;  // global triangle id -> position in `tris` (leaf order)
     int n_tris = 0, n_nodes = 0, n_mesh_objects = 0, max_depth = 0;
     float center[3] = {0, 0, 0}, half[3] = {0, 0, 0};  // root box
+    float bs_radius = 0;  // radius of a sphere around `center` that contains every triangle (rounded up)
 };
 
 inline float bits_of(int32_t v) {
@@ -272,11 +281,29 @@ inline void build_mesh_image(const srt_object* objects, size_t count, const std:
             wide[(size_t)wide_of[k]] = w;
         }
     }
+    // triangle storage order: breadth-first like the nodes — for every wide node, the triangles of its leaf
+    // children in child order — so that a node needs one "first leaf triangle" instead of a reference per child
+    std::vector<int32_t> newpos(tris.size(), -1);  // position in `tris` (build order) -> position in the output
+    std::vector<int32_t> first_tri(wide.size(), 0), first_inner(wide.size(), 0);
+    {
+        int32_t next = 0;
+        for (size_t k = 0; k < wide.size(); ++k) {
+            first_tri[k] = next;
+            first_inner[k] = 0;
+            for (int c = 0; c < wide[k].n; ++c) {
+                const Node& ch = nodes[wide[k].child[c]];
+                if (ch.b > 0)
+                    for (int t = 0; t < ch.b; ++t) newpos[(size_t)(ch.a + t)] = next++;
+                else if (first_inner[k] == 0)
+                    first_inner[k] = wide_of[wide[k].child[c]];
+            }
+        }
+    }
     // quantize: child boxes on a 256^3 grid spanned by the node's own box.  origin = node.lo (float),
     // cell = 2^e per axis (the smallest power of two with 255 cells >= extent); lo is rounded down,
     // hi up, in exact double arithmetic, so  origin + q*cell  (as real numbers) encloses the child.
     out.n_nodes = (int)wide.size();
-    out.nodes.assign(wide.size() * 6, make_float4(0, 0, 0, 0));
+    out.nodes.assign(wide.size() * NODE_VEC4, make_float4(0, 0, 0, 0));
     for (size_t k = 0; k < wide.size(); ++k) {
         const Wide& w = wide[k];
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -295,11 +322,11 @@ inline void build_mesh_image(const srt_object* objects, size_t count, const std:
             cell[ax] = ldexp(1.0, e);
         }
         uint8_t q[6][8];
-        int32_t ref[8];
+        uint32_t innermask = 0, leafmask = 0, counts = 0;
+        int expect_inner = first_inner[k];
         for (int c = 0; c < 8; ++c) {
-            if (c >= w.n) {  // absent child: inverted box, ref 0 (the root is nobody's child)
+            if (c >= w.n) {  // absent child: inverted box, in neither mask
                 for (int ax = 0; ax < 3; ++ax) q[ax][c] = 255, q[3 + ax][c] = 0;
-                ref[c] = 0;
                 continue;
             }
             const Node& ch = nodes[w.child[c]];
@@ -311,29 +338,52 @@ inline void build_mesh_image(const srt_object* objects, size_t count, const std:
                 q[ax][c] = (uint8_t)ql;
                 q[3 + ax][c] = (uint8_t)qh;
             }
-            ref[c] = ch.b > 0 ? -(1 + ch.a * 4 + (ch.b - 1)) : wide_of[w.child[c]];
+            if (ch.b > 0) {
+                leafmask |= 1u << c;
+                counts |= (uint32_t)(ch.b - 1) << (2 * c);
+            } else {
+                innermask |= 1u << c;
+                if (wide_of[w.child[c]] != expect_inner++) throw std::logic_error("BVH: inner children are not consecutive");
+            }
         }
         auto pack4 = [&](int row, int first) {
             return bits_of((int32_t)((uint32_t)q[row][first] | ((uint32_t)q[row][first + 1] << 8) | ((uint32_t)q[row][first + 2] << 16) |
                                      ((uint32_t)q[row][first + 3] << 24)));
         };
-        out.nodes[6 * k + 0] = make_float4(lo[0], lo[1], lo[2], bits_of((int32_t)(expo[0] | (expo[1] << 8) | (expo[2] << 16))));
-        out.nodes[6 * k + 1] = make_float4(pack4(0, 0), pack4(0, 4), pack4(1, 0), pack4(1, 4));  // lo.x[0..7], lo.y[0..7]
-        out.nodes[6 * k + 2] = make_float4(pack4(2, 0), pack4(2, 4), pack4(3, 0), pack4(3, 4));  // lo.z, hi.x
-        out.nodes[6 * k + 3] = make_float4(pack4(4, 0), pack4(4, 4), pack4(5, 0), pack4(5, 4));  // hi.y, hi.z
-        out.nodes[6 * k + 4] = make_float4(bits_of(ref[0]), bits_of(ref[1]), bits_of(ref[2]), bits_of(ref[3]));
-        out.nodes[6 * k + 5] = make_float4(bits_of(ref[4]), bits_of(ref[5]), bits_of(ref[6]), bits_of(ref[7]));
+        float4* nd = &out.nodes[NODE_VEC4 * k];
+        nd[0] = make_float4(lo[0], lo[1], lo[2], bits_of((int32_t)(expo[0] | (expo[1] << 8) | (expo[2] << 16) | (innermask << 24))));
+        nd[1] = make_float4(bits_of(first_inner[k]), bits_of(first_tri[k]), bits_of((int32_t)(leafmask | (counts << 8))), 0.0f);
+        nd[2] = make_float4(pack4(0, 0), pack4(0, 4), pack4(1, 0), pack4(1, 4));  // lo.x[0..7], lo.y[0..7]
+        nd[3] = make_float4(pack4(2, 0), pack4(2, 4), pack4(3, 0), pack4(3, 4));  // lo.z, hi.x
+        nd[4] = make_float4(pack4(4, 0), pack4(4, 4), pack4(5, 0), pack4(5, 4));  // hi.y, hi.z
     }
     out.tris.resize(tris.size() * 3);
     out.gidpos.assign(tris.size(), 0);
-    for (size_t k = 0; k < tris.size(); ++k) out.gidpos[(size_t)tris[k].gid] = (int32_t)k;
     for (size_t k = 0; k < tris.size(); ++k) {
-        out.tris[3 * k] = make_float4(tris[k].v0[0], tris[k].v0[1], tris[k].v0[2], bits_of(tris[k].prim));
-        out.tris[3 * k + 1] = make_float4(tris[k].e1[0], tris[k].e1[1], tris[k].e1[2], bits_of(tris[k].gid));
-        out.tris[3 * k + 2] = make_float4(tris[k].e2[0], tris[k].e2[1], tris[k].e2[2], bits_of(tris[k].ord));
+        const size_t pos = (size_t)newpos[k];
+        out.gidpos[(size_t)tris[k].gid] = (int32_t)pos;
+        out.tris[3 * pos] = make_float4(tris[k].v0[0], tris[k].v0[1], tris[k].v0[2], bits_of(tris[k].prim));
+        out.tris[3 * pos + 1] = make_float4(tris[k].e1[0], tris[k].e1[1], tris[k].e1[2], bits_of(tris[k].gid));
+        out.tris[3 * pos + 2] = make_float4(tris[k].e2[0], tris[k].e2[1], tris[k].e2[2], bits_of(tris[k].ord));
+    }
+    for (int ax = 0; ax < 3; ++ax) out.center[ax] = 0.5f * (nodes[0].lo[ax] + nodes[0].hi[ax]);
+    {  // bounding sphere around the root box's centre: max vertex distance in double, inflated and rounded up
+        double r2 = 0;
+        for (const Tri& t : tris)
+            for (int q = 0; q < 3; ++q) {
+                double d2 = 0;
+                for (int ax = 0; ax < 3; ++ax) {
+                    const double v = (double)t.v0[ax] + (q == 1 ? (double)t.e1[ax] : q == 2 ? (double)t.e2[ax] : 0.0);
+                    d2 += (v - (double)out.center[ax]) * (v - (double)out.center[ax]);
+                }
+                r2 = std::max(r2, d2);
+            }
+        // (v0 + e1 in double differs from the float vertex by <= 1 ulp of the coordinate: covered by the 1e-5 inflation)
+        const double r = sqrt(r2) * (1.0 + 1e-5) + 1e-30;
+        out.bs_radius = (float)r;
+        if ((double)out.bs_radius < r) out.bs_radius = nextafterf(out.bs_radius, INFINITY);
     }
     for (int ax = 0; ax < 3; ++ax) {
-        out.center[ax] = 0.5f * (nodes[0].lo[ax] + nodes[0].hi[ax]);
         // half extent rounded up so that [center - half, center + half] contains the root box
         float h = std::max(nodes[0].hi[ax] - out.center[ax], out.center[ax] - nodes[0].lo[ax]);
         out.half[ax] = nextafterf(h * 1.000001f, INFINITY);

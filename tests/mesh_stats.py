@@ -30,6 +30,12 @@ L.srt_debug_read_stats(out)
 names = ["mesh phases (waves)", "go lanes", "node rounds", "node items", "leaf rounds", "leaf items", "overflows", "strict-mode entries"]
 for k, v in zip(names, out): print("%-22s %d" % (k, v))
 print("rays %d  kernel %.3f ms" % (st.rays, st.kernel_ms))
+if os.environ.get("SRT_STATS_MODE") == "4":
+    o = list(out)
+    ph, nr, lr = max(o[6], 1), max(o[4], 1), max(o[5], 1)
+    print("phases %d: %.0f cycles each | node rounds %.1f per phase, %.0f cycles each (%.0f until the node data is there) | leaf rounds %.1f per phase, %.0f cycles each | outside rounds %.0f cycles per phase" %
+          (o[6], o[0] / ph, o[4] / ph, o[1] / nr, o[3] / nr, o[5] / ph, o[2] / lr, (o[0] - o[1] - o[2]) / ph))
+    sys.exit(0)
 if os.environ.get("SRT_STATS_MODE") == "2":
     print("histogram by rays entering the phase (1-2, 3-8, 9-32, 33-64): phases", list(out[:4]), "rounds", list(out[4:]))
     sys.exit(0)

@@ -47,12 +47,15 @@ int main() {
             std::vector<int> stack{0};
             while (!stack.empty()) {
                 int nd = stack.back(); stack.pop_back();
+                const float4 h0 = mi.nodes[srt::NODE_VEC4 * (size_t)nd], h1 = mi.nodes[srt::NODE_VEC4 * (size_t)nd + 1];
+                uint32_t w0, first_inner, first_tri, lw;
+                memcpy(&w0, &h0.w, 4); memcpy(&first_inner, &h1.x, 4); memcpy(&first_tri, &h1.y, 4); memcpy(&lw, &h1.z, 4);
+                const uint32_t innermask = w0 >> 24, leafmask = lw & 255u, counts = lw >> 8;
+                if (innermask & leafmask) { std::printf("child both inner and leaf\n"); return 1; }
+                int ni = 0; uint32_t tri = first_tri;
                 for (int c = 0; c < 8; ++c) {
-                    const float4 r = mi.nodes[6 * (size_t)nd + 4 + c / 4];
-                    const float rf = c % 4 == 0 ? r.x : c % 4 == 1 ? r.y : c % 4 == 2 ? r.z : r.w;
-                    int32_t ref; memcpy(&ref, &rf, 4);
-                    if (ref > 0) { if (ref >= mi.n_nodes) { std::printf("bad node ref\n"); return 1; } stack.push_back(ref); }
-                    else if (ref < 0) { int v = -ref - 1, first = v >> 2, cnt = (v & 3) + 1; for (int k = 0; k < cnt; ++k) { if (first + k >= mi.n_tris) { std::printf("bad leaf\n"); return 1; } seen[(size_t)first + k]++; } }
+                    if (innermask >> c & 1u) { int ref = (int)first_inner + ni++; if (ref <= nd || ref >= mi.n_nodes) { std::printf("bad node ref\n"); return 1; } stack.push_back(ref); }
+                    else if (leafmask >> c & 1u) { int cnt = 1 + (int)((counts >> (2 * c)) & 3u); for (int k = 0; k < cnt; ++k) { if ((int)tri >= mi.n_tris) { std::printf("bad leaf\n"); return 1; } seen[(size_t)tri++]++; } }
                 }
             }
             for (int k = 0; k < mi.n_tris; ++k) if (seen[(size_t)k] != 1) { std::printf("triangle %d seen %d times (it %d)\n", k, seen[(size_t)k], it); return 1; }
