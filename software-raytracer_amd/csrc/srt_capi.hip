@@ -111,6 +111,7 @@ struct srt_context {
     // cost-ordered dispatch: a launch may record the ray count of every block of tiles; once that copy has
     // arrived (polled, never waited for) later launches of the same grid start the expensive blocks first
     uint32_t* d_wg_cost = nullptr;
+    uint32_t* d_wg_est = nullptr;    // estimated block costs (block_cost_kernel), input of order_sort_kernel
     uint32_t* d_wg_order = nullptr;
     uint32_t* h_wg_cost = nullptr;   // pinned
     uint32_t* h_wg_order = nullptr;  // pinned
@@ -119,6 +120,7 @@ struct srt_context {
     unsigned rec_gx = 0, rec_gy = 0;      // grid of the recording in flight
     bool recording = false;               // a cost copy is in flight (ev_cost)
     bool order_stale = true;              // scene / camera changed since the costs were recorded
+    bool estimate_stale = true;           // the scene changed since the order was last estimated on the device
     bool order_disabled = false;          // buffers for the feedback could not be allocated
     hipEvent_t ev_cost = nullptr, ev_order = nullptr;
 
@@ -262,6 +264,7 @@ int srt_destroy(srt_context* ctx) {
     if (ctx->d_pick) (void)hipFree(ctx->d_pick);
     if (ctx->d_samples) (void)hipFree(ctx->d_samples);
     if (ctx->d_wg_cost) (void)hipFree(ctx->d_wg_cost);
+    if (ctx->d_wg_est) (void)hipFree(ctx->d_wg_est);
     if (ctx->d_wg_order) (void)hipFree(ctx->d_wg_order);
     if (ctx->h_wg_cost) (void)hipHostFree(ctx->h_wg_cost);
     if (ctx->h_wg_order) (void)hipHostFree(ctx->h_wg_order);
@@ -355,6 +358,7 @@ static int set_scene_impl(srt_context* ctx, const srt_object* objects, size_t co
     }
     ctx->scene_set = true;
     ctx->order_stale = true;
+    ctx->estimate_stale = true;
     return SRT_OK;
 }
 
@@ -408,7 +412,9 @@ int srt_set_camera(srt_context* ctx, const srt_camera* camera) {
     if (!ctx || !camera) return SRT_ERR_INVALID_ARG;
     ctx->camera.cam = *camera;
     ctx->camera.set = true;
-    ctx->order_stale = true;  // block costs change with the view (the old order stays in use until new costs arrive)
+    // block costs change with the view: the order learned for the previous view stays in use (for a moving camera it is
+    // a better guess than a fresh probe estimate) until the next launch has recorded new costs
+    ctx->order_stale = true;
     return SRT_OK;
 }
 
@@ -612,16 +618,18 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
         if (nwg > ctx->wg_capacity) {
             SRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->d_wg_cost) (void)hipFree(ctx->d_wg_cost);
+            if (ctx->d_wg_est) (void)hipFree(ctx->d_wg_est);
             if (ctx->d_wg_order) (void)hipFree(ctx->d_wg_order);
             if (ctx->h_wg_cost) (void)hipHostFree(ctx->h_wg_cost);
             if (ctx->h_wg_order) (void)hipHostFree(ctx->h_wg_order);
-            ctx->d_wg_cost = ctx->d_wg_order = ctx->h_wg_cost = ctx->h_wg_order = nullptr;
+            ctx->d_wg_cost = ctx->d_wg_est = ctx->d_wg_order = ctx->h_wg_cost = ctx->h_wg_order = nullptr;
             ctx->wg_capacity = 0;
             ctx->order_gx = ctx->order_gy = 0;
             ctx->recording = false;
             // an optimisation must not be able to fail a render: if anything here cannot be had (pinned host
             // memory, for one), the handle simply keeps the natural order from now on
             const bool ok = hipMalloc((void**)&ctx->d_wg_cost, nwg * 4) == hipSuccess && hipMalloc((void**)&ctx->d_wg_order, nwg * 4) == hipSuccess &&
+                            hipMalloc((void**)&ctx->d_wg_est, 2 * nwg * 4) == hipSuccess &&  // raw + smoothed
                             hipHostMalloc((void**)&ctx->h_wg_cost, nwg * 4, hipHostMallocDefault) == hipSuccess &&
                             hipHostMalloc((void**)&ctx->h_wg_order, nwg * 4, hipHostMallocDefault) == hipSuccess &&
                             (ctx->ev_cost || hipEventCreateWithFlags(&ctx->ev_cost, hipEventDisableTiming) == hipSuccess) &&
@@ -668,6 +676,26 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             SRT_HIP(ctx, hipMemcpyAsync(ctx->d_wg_order, ctx->h_wg_order, n * 4, hipMemcpyHostToDevice, ctx->stream));
             SRT_HIP(ctx, hipEventRecord(ctx->ev_order, ctx->stream));
             ctx->order_gx = ctx->rec_gx, ctx->order_gy = ctx->rec_gy;
+        }
+        // No recorded costs for this frame yet (first launch, or the scene / camera has changed): estimate the blocks'
+        // costs on the device — 16 one-sample probe paths per block, block_cost_kernel — and sort them there (order_sort_kernel);
+        // both run on the launch stream ahead of the frame, nothing comes back to the host.  Measured with warm clocks:
+        // first launch of a frame vs the learned order: config 4 +13 % -> see DESIGN.md, Scene1 +3 %.
+        if (dev_switches().host_order && arrived != hipSuccess && (ctx->estimate_stale || ctx->order_gx != grid.x || ctx->order_gy != grid.y)) {
+            const size_t image_bytes = (size_t)(K.scene_vec4 > 0 ? K.scene_vec4 : 1) * sizeof(float4);
+            const size_t est_lds = (ctx->pick_in_lds[img] ? image_bytes : 0) + srt::WAVE_SCRATCH_BYTES + srt::MESH_WAVE_BYTES;
+            if (ctx->pick_in_lds[img])
+                hipLaunchKernelGGL(srt::block_cost_kernel<true>, dim3((unsigned)((nwg + 3) / 4)), dim3(64), est_lds, ctx->stream, K, ctx->d_wg_est, (int)grid.x, (int)nwg);
+            else
+                hipLaunchKernelGGL(srt::block_cost_kernel<false>, dim3((unsigned)((nwg + 3) / 4)), dim3(64), est_lds, ctx->stream, K, ctx->d_wg_est, (int)grid.x, (int)nwg);
+            hipLaunchKernelGGL(srt::smooth_cost_kernel, dim3((unsigned)((nwg + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_wg_est, ctx->d_wg_est + nwg, (int)nwg, (int)grid.x);
+            hipLaunchKernelGGL(srt::order_sort_kernel, dim3(1), dim3(srt::ORDER_SORT_THREADS), 0, ctx->stream, ctx->d_wg_est + nwg, ctx->d_wg_order, (int)nwg);
+            if (hipGetLastError() == hipSuccess) {
+                ctx->order_gx = grid.x, ctx->order_gy = grid.y;
+                ctx->estimate_stale = false;
+            } else {
+                ctx->order_gx = ctx->order_gy = 0;  // an optimisation must not fail the render: natural order
+            }
         }
         if (ctx->order_gx == grid.x && ctx->order_gy == grid.y) K.wg_order = ctx->d_wg_order;
         if (!ctx->recording && (ctx->order_stale || ctx->order_gx != grid.x || ctx->order_gy != grid.y)) {

@@ -1307,4 +1307,150 @@ __global__ void __launch_bounds__(64) pick_kernel(const KernelParams P, int px, 
     }
 }
 
+// ---- initial dispatch order, before any launch of a frame has recorded block costs -----------------------
+// A wave probes four blocks of tiles, 16 lanes each: every lane traces ONE path (the first sample of a pixel of
+// a 4 x 4 grid over the block; same ray generation, materials and random stream as the real thing, no colours)
+// and the block's cost estimate is the number of rays of its 16 paths, rays that end on a mesh counted four
+// times.  That is 1/16 of the pixels at one sample — well under 1 % of a 32-spp frame — and it is what the order
+// needs: where the long paths are (reflections, rooms, meshes), which the primary hit alone does not tell
+// (measured: ordering by primary hits left the first launch of config 4 13 % and of Scene3 10 % behind the
+// learned order).  Any order gives the same image.
+constexpr int ORDER_BUCKETS = 16, ORDER_SORT_THREADS = 512;
+template <bool SCENE_LDS>
+__global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, uint32_t* cost, int blocks_x, int n_blocks) {
+    extern __shared__ float4 lds_scene[];
+    if constexpr (SCENE_LDS) {
+        for (int i = threadIdx.x; i < P.scene_vec4; i += 64) lds_scene[i] = P.scene[i];
+        __syncthreads();
+    }
+    const Lds S = make_lds<SCENE_LDS>(P, lds_scene, 1, 0);
+    const int lane = threadIdx.x, block = (int)blockIdx.x * 4 + (lane >> 4), k = lane & 15;
+    const int bx = block % blocks_x, by = block / blocks_x;
+    const int block_h = P.tile_h * WG_TILES_Y;
+    const int tx = bx * WG_W + 4 * (k & 3) + 2, ty = by * block_h + ((k >> 2) * block_h) / 4 + block_h / 8;
+    const bool in_range = block < n_blocks && tx < P.width && ty < P.rows;
+    const int x = in_range ? tx : 0, y = in_range ? P.y0 + ty : P.y0;
+    float nX = ((float)x / (float)P.width) * 2 - 1;
+    float nY = ((float)y / (float)P.height) * 2 - 1;
+    V3 u = v3(P.right_rd[0] * nX, P.right_rd[1] * nX, P.right_rd[2] * nX);
+    V3 vv = v3(P.up_ld[0] * nY, P.up_ld[1] * nY, P.up_ld[2] * nY);
+    V3 sray = normalized(v3((u.x + vv.x) + P.fwd_clip[0], (u.y + vv.y) + P.fwd_clip[1], (u.z + vv.z) + P.fwd_clip[2]));
+    bool deferred = false;
+#if defined(SRT_STATS) && SRT_STATS == 3
+    Prof prof{};
+#endif
+    Hit h = closest_hit<true>(S, P, v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]), sray, in_range, 1, deferred SRT_PROF_ARG);
+    const int first_mesh_prim = S.nsT + S.nb;
+    unsigned c = in_range ? 1u : 0u;
+    bool alive = in_range && h.prim >= 0 && P.max_bounces > 0 && !(P.flags & 4u);
+    uint32_t rng = srt_rng_key(P.seed, (uint32_t)(x + y * P.width), P.first_sample);
+    float spec = 0.0f;
+    if (alive) {
+        spec = (S.mat(h.prim, 0).y >= rand_unit(srt_mix32(rng) >> 17)) ? 1.0f : 0.0f;
+        rng += 0x9E3779B9U;
+        c += h.prim >= first_mesh_prim ? 3u : 0u;
+    }
+    for (int bounce = 0; bounce < P.max_bounces && __builtin_amdgcn_ballot_w64(alive) != 0ull; ++bounce) {
+        V3 o = v3(0, 0, 0);
+        if (alive) {  // the bounce step of the path pool (Raytracer.cpp:172-177), directions only
+            const float k2 = 2 * dot3(sray, h.n);
+            const V3 refl = v3(sray.x - h.n.x * k2, sray.y - h.n.y * k2, sray.z - h.n.z * k2);
+            V3 sr = v3((rand_unit(srt_mix32(rng) >> 17) - 0.5f) * 2, (rand_unit(srt_mix32(rng + 0x9E3779B9U) >> 17) - 0.5f) * 2,
+                       (rand_unit(srt_mix32(rng + 2u * 0x9E3779B9U) >> 17) - 0.5f) * 2);
+            rng += 3u * 0x9E3779B9U;
+            sr = normalized(sr);
+            if (dot3(sr, h.n) < 0) sr = v3(sr.x * -1, sr.y * -1, sr.z * -1);
+            const float tt = S.mat(h.prim, 0).x * spec;
+            sray = normalized(v3(sr.x * (1 - tt) + refl.x * tt, sr.y * (1 - tt) + refl.y * tt, sr.z * (1 - tt) + refl.z * tt));
+            o = v3(h.p.x + h.n.x * .00001f, h.p.y + h.n.y * .00001f, h.p.z + h.n.z * .00001f);
+        }
+        const Hit g = closest_hit<true>(S, P, o, sray, alive, 1, deferred SRT_PROF_ARG);
+        if (alive) {
+            c += g.prim >= first_mesh_prim ? 4u : 1u;
+            if (g.prim < 0) {
+                alive = false;
+            } else {
+                spec = (S.mat(g.prim, 0).y >= rand_unit(srt_mix32(rng) >> 17)) ? 1.0f : 0.0f;
+                rng += 0x9E3779B9U;
+                h = g;
+            }
+        }
+    }
+    for (int off = 8; off > 0; off >>= 1) c += __shfl_down(c, off, 16);
+    if (k == 0 && block < n_blocks) cost[block] = c;
+}
+
+// The probe estimate is 16 one-sample paths per block: noisy.  Costs vary smoothly over the image except at object
+// edges, so every block gets the sum over its 3 x 3 neighbourhood (out[b], blocks_x blocks per row) ...
+__global__ void __launch_bounds__(256) smooth_cost_kernel(const uint32_t* cost, uint32_t* out, int n, int blocks_x) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= n) return;
+    const int bx = i % blocks_x, by = i / blocks_x, rows = (n + blocks_x - 1) / blocks_x;
+    uint32_t sum = 0u;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int x = bx + dx < 0 ? 0 : bx + dx >= blocks_x ? blocks_x - 1 : bx + dx, y = by + dy < 0 ? 0 : by + dy >= rows ? rows - 1 : by + dy;
+            const int j = y * blocks_x + x;
+            sum += cost[j < n ? j : i];
+        }
+    out[i] = sum;
+}
+
+// ... and the blocks are sorted into only ORDER_BUCKETS linear cost buckets, dearest first, by a STABLE counting sort
+// (one workgroup; n is a few thousand to a few hundred thousand): neighbours of similar cost stay in their natural
+// order.  (The costs RECORDED by a launch are exact; the host sorts those into 128 buckets, srt_capi.hip.)
+__global__ void __launch_bounds__(ORDER_SORT_THREADS) order_sort_kernel(const uint32_t* cost, uint32_t* order, int n) {
+    __shared__ uint32_t hist[ORDER_BUCKETS * ORDER_SORT_THREADS];  // [bucket][thread]
+    __shared__ uint32_t part[ORDER_SORT_THREADS];
+    __shared__ uint32_t red[2 * ORDER_SORT_THREADS / 64];
+    const int t = threadIdx.x;
+    const int chunk = (n + ORDER_SORT_THREADS - 1) / ORDER_SORT_THREADS, b0 = t * chunk < n ? t * chunk : n, b1 = b0 + chunk < n ? b0 + chunk : n;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (int i = b0; i < b1; ++i) {
+        const uint32_t c = cost[i];
+        lo = c < lo ? c : lo, hi = c > hi ? c : hi;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t l2 = __shfl_down(lo, off), h2 = __shfl_down(hi, off);
+        lo = l2 < lo ? l2 : lo, hi = h2 > hi ? h2 : hi;
+    }
+    if ((t & 63) == 0) red[t >> 6] = lo, red[ORDER_SORT_THREADS / 64 + (t >> 6)] = hi;
+    for (int i = t; i < ORDER_BUCKETS * ORDER_SORT_THREADS; i += ORDER_SORT_THREADS) hist[i] = 0u;
+    __syncthreads();
+    lo = 0xFFFFFFFFu, hi = 0u;
+    for (int i = 0; i < ORDER_SORT_THREADS / 64; ++i) {
+        lo = red[i] < lo ? red[i] : lo;
+        hi = red[ORDER_SORT_THREADS / 64 + i] > hi ? red[ORDER_SORT_THREADS / 64 + i] : hi;
+    }
+    const float scale = hi > lo ? (float)ORDER_BUCKETS / ((float)(hi - lo) + 1.0f) : 0.0f;
+    auto bucket = [&](uint32_t c) {
+        int b = (ORDER_BUCKETS - 1) - (int)((float)(c - lo) * scale);
+        return b < 0 ? 0 : b > ORDER_BUCKETS - 1 ? ORDER_BUCKETS - 1 : b;
+    };
+    for (int i = b0; i < b1; ++i) hist[bucket(cost[i]) * ORDER_SORT_THREADS + t] += 1u;
+    __syncthreads();
+    // exclusive prefix sum over the flattened [bucket][thread] table: thread t owns ORDER_BUCKETS consecutive entries
+    uint32_t sum = 0u;
+    for (int i = 0; i < ORDER_BUCKETS; ++i) sum += hist[t * ORDER_BUCKETS + i];
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < ORDER_SORT_THREADS; off <<= 1) {
+        const uint32_t v = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t base = part[t] - sum;
+    for (int i = 0; i < ORDER_BUCKETS; ++i) {
+        const uint32_t v = hist[t * ORDER_BUCKETS + i];
+        hist[t * ORDER_BUCKETS + i] = base;
+        base += v;
+    }
+    __syncthreads();
+    for (int i = b0; i < b1; ++i) {
+        const int b = bucket(cost[i]);
+        order[hist[b * ORDER_SORT_THREADS + t]++] = (uint32_t)i;
+    }
+}
+
 }  // namespace srt
