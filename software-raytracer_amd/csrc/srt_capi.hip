@@ -564,7 +564,8 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     const long long wg_y8 = (K.rows + srt::WG_H - 1) / srt::WG_H, wg8 = wg_x * wg_y8;
     int chunk = 0, chunks = 1;
     // (scenes with meshes from 32 spp: their few, heavy tiles profit earlier — config 4 at 32 spp +20 %)
-    if (tile_env == 0 && defer_env != 0 && (p->sample_count >= 64 || defer_env > 0 || K.n_tris > 0) && p->sample_count >= 32) {
+    // (progressive blocks, steps > 1, are traced once per block by the multi-sample instantiation: no sample chunks)
+    if (tile_env == 0 && defer_env != 0 && (p->sample_count >= 64 || defer_env > 0 || K.n_tris > 0) && p->sample_count >= 32 && K.steps <= 1) {
         long long c = (96LL * ctx->cu_count + wg8 - 1) / wg8;  // about 24 k workgroups in flight over the launch
         if (c > p->sample_count / 16) c = p->sample_count / 16;
         if (c >= 2 || defer_env > 0) {
@@ -708,7 +709,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     // instantiation: mesh or not, scene image in LDS or HBM, full tiles / small tiles (multi-sample
     // hand-out) / sample chunks; variants 1 / 3 are a development aid for in-process A/B timing.
     // All are bit-identical.
-    const bool in_lds = ctx->scene_in_lds[img], multi = tile_h < srt::TILE_H;
+    const bool in_lds = ctx->scene_in_lds[img], multi = tile_h < srt::TILE_H || (K.steps > 1 && !(K.flags & SRT_RENDER_PREVIEW));
     auto launch = [&](auto k_lds, auto k_lds_multi, auto k_lds_defer, auto k_hbm, auto k_hbm_multi, auto k_hbm_defer) {
         if (in_lds && defer) hipLaunchKernelGGL(k_lds_defer, grid, block, lds_bytes, ctx->stream, K);
         else if (in_lds && multi) hipLaunchKernelGGL(k_lds_multi, grid, block, lds_bytes, ctx->stream, K);

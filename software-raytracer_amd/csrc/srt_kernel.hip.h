@@ -955,6 +955,21 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         ay = (y / P.steps) * P.steps;
     }
     const uint32_t rng_pixel = (uint32_t)(ax + ay * W);
+    // Blocks are traced ONCE per wave tile, by the first lane of the tile that lies in the block (its leader), and
+    // every pixel of the block folds the leader's sample colours into its own running mean (renderArea :239-248 does
+    // exactly that: one RaytraceScene per block, one SetScreenPixel per pixel).  A block that straddles tiles is traced
+    // once in each.  Launches with steps > 1 use the MULTI instantiation (few slots per tile, several samples each).
+    int lead_lane = lane;
+    if constexpr (MULTI) {
+        if (P.steps > 1 && !(P.flags & 4u)) {  // (the preview shader traces nothing: every pixel shades for itself)
+            const uint32_t key = in_range ? rng_pixel : 0xFFFFFFFFu - (uint32_t)lane;  // lanes without a pixel lead themselves
+            unsigned long long same = 0ull;
+            for (int i = 0; i < 64; ++i)
+                if ((uint32_t)__builtin_amdgcn_readlane((int)key, i) == key) same |= 1ull << i;
+            lead_lane = __builtin_ctzll(same);
+        }
+    }
+    const bool is_leader = lead_lane == lane;
 
     // ---- GetRayDirection (Raytracer.cpp:106-122) ----------------------------------
     float nX = ((float)ax / (float)W) * 2 - 1;
@@ -982,8 +997,9 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     //  primary miss -> env(dir0) every frame (:143-145); MAXBOUNCES == 0 -> EmissiveColor (:162,212)
     //  SIMPLEDRAW -> the one-ray preview shader (:147-160), no random draws
     const bool preview = (P.flags & 4u) != 0;
-    const bool traced = in_range && h0.prim >= 0 && B > 0 && !preview;
-    if (in_range && !traced && (!DEFER || blockIdx.z == 0)) {  // (chunked: once, by the first chunk, for all samples)
+    const bool pix_traced = in_range && h0.prim >= 0 && B > 0 && !preview;  // (the same for every pixel of a block)
+    const bool traced = pix_traced && is_leader;
+    if (in_range && !pix_traced && (!DEFER || blockIdx.z == 0)) {  // (chunked: once, by the first chunk, for all samples)
         RGB c;
         if (h0.prim < 0) {
             c = environment(P, dir0);
@@ -1018,7 +1034,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         }
         float4 acc = reset ? make_float4(0, 0, 0, 0) : P.accumulator[pixel];
         for (uint32_t i = 0; i < P.sample_count; ++i) accumulate(acc, c, i);
-        rays += P.sample_count;
+        if (is_leader) rays += P.sample_count;  // one GetClosestObject call per block and frame
         write_pixel(pixel, acc);
     }
 
@@ -1057,7 +1073,15 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         const bool owner = lane < n_hit;
         uint32_t own_pixel = 0, own_done = owner ? 0u : count;  // samples folded so far
         float4 acc = make_float4(0, 0, 0, 0);
-        if (owner) {
+        // progressive blocks: a slot is a block, and every PIXEL lane of the block folds the slot's colours into the
+        // running mean of its own pixel, in step with the slot's owner (same ring entries, same test, same iteration)
+        const bool blocks = MULTI && P.steps > 1 && !(P.flags & 4u);
+        const bool fold_px = blocks && pix_traced;
+        const int fslot = __builtin_popcountll(hitmask & ((1ull << lead_lane) - 1ull));  // the leader's slot
+        uint32_t fdone = fold_px ? 0u : count;
+        if (blocks) {
+            if (fold_px && !reset) acc = P.accumulator[pixel];
+        } else if (owner) {
             own_pixel = __float_as_uint(rec[lane * 12 + 11]);
             if (!DEFER && !reset) acc = P.accumulator[own_pixel];
         }
@@ -1086,6 +1110,23 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 if (own_done < count) {
                     e = ring[ring_row(own_done) * n_hit + lane];
                     ready = __float_as_uint(e.w) == own_done;
+                }
+                if constexpr (MULTI) {
+                    if (blocks) {  // the pixels of a block fold; the owner only advances the slot's fold point
+                        bool ready_px = false;
+                        float4 f = make_float4(0, 0, 0, 0);
+                        if (fdone < count) {
+                            f = ring[ring_row(fdone) * n_hit + fslot];
+                            ready_px = __float_as_uint(f.w) == fdone;
+                        }
+                        if (__builtin_amdgcn_ballot_w64(ready | ready_px) == 0ull) break;
+                        if (ready_px) {
+                            accumulate(acc, RGB{f.x, f.y, f.z}, fdone);
+                            ++fdone;
+                        }
+                        if (ready) ++own_done;
+                        continue;
+                    }
                 }
                 if (__builtin_amdgcn_ballot_w64(ready) == 0ull) break;
                 if (ready) {
@@ -1227,7 +1268,11 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (!DEFER && owner) write_pixel(own_pixel, acc);
+        if (blocks) {
+            if (fold_px) write_pixel(pixel, acc);
+        } else if (!DEFER && owner) {
+            write_pixel(own_pixel, acc);
+        }
     }
 
 #if defined(SRT_STATS) && SRT_STATS == 3
