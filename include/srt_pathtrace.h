@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SRT_ABI_VERSION 3
+#define SRT_ABI_VERSION 4
 
 typedef enum srt_status {
     SRT_OK = 0,
@@ -209,6 +209,18 @@ int srt_read_framebuffer(srt_context* ctx, void* dst, size_t pitch_bytes, int ro
 /* colorBuffer (:60): W*H float4 (r,g,b,a), index x + y*W, scene rows. Wait + copy. */
 int srt_read_accumulator(srt_context* ctx, float* dst_rgba);
 int srt_write_accumulator(srt_context* ctx, const float* src_rgba);
+
+/* ---- multi-GPU row stripes in ONE process -----------------------------
+ * The reference splits a frame over 16 worker threads that write disjoint columns of one
+ * surface (Raytracer.cpp:330-342); across GPUs the split is disjoint bands of MEMORY rows,
+ * one context per GPU, and this call is the gather: it copies memory rows
+ * [row_begin,row_end) of `src`'s framebuffer into the same rows of `dst`'s framebuffer,
+ * device to device (a peer copy over xGMI when the two contexts live on different GPUs),
+ * enqueued on src's stream behind its render; dst's stream is made to wait for it, so a
+ * following srt_read_framebuffer(dst) sees the band.  Both contexts must have the same
+ * width and height.  (Across PROCESSES the same gather is one RCCL collective:
+ * software-raytracer_amd/stripes.py, bench.py --gpus N.) */
+int srt_gather_band(srt_context* dst, srt_context* src, int row_begin, int row_end);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ _LIB = os.path.join(_PKG, "libsrt_pathtrace.so")
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_OOM = range(6)
 OBJ_NONE, OBJ_SPHERE, OBJ_BOX, OBJ_MESH = 0, 1, 2, 3
 RENDER_RESET, RENDER_COUNT_RAYS, RENDER_PREVIEW = 1, 2, 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/srt_pathtrace.h declares (tests check the library exports them all)
 EXPORTS = [
@@ -24,7 +24,7 @@ EXPORTS = [
     "srt_set_scene", "srt_set_meshes", "srt_set_environment", "srt_environment_default", "srt_set_camera",
     "srt_set_stream", "srt_bind_output", "srt_device_framebuffer", "srt_device_accumulator",
     "srt_render", "srt_wait", "srt_poll", "srt_get_stats", "srt_pick", "srt_read_framebuffer",
-    "srt_read_accumulator", "srt_write_accumulator",
+    "srt_read_accumulator", "srt_write_accumulator", "srt_gather_band",
 ]
 
 
@@ -169,6 +169,7 @@ def load_library():
     L.srt_read_framebuffer.argtypes = [ctx, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
     L.srt_read_accumulator.argtypes = [ctx, C.POINTER(C.c_float)]
     L.srt_write_accumulator.argtypes = [ctx, C.POINTER(C.c_float)]
+    L.srt_gather_band.argtypes = [ctx, ctx, C.c_int, C.c_int]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name != "srt_last_error":
@@ -298,6 +299,10 @@ class PathTracer:
         a = np.ascontiguousarray(arr, dtype=np.float32)
         assert a.shape == (self.height, self.width, 4)
         self._ck(self.L.srt_write_accumulator(self._h, a.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def gather_band_from(self, src, rows):
+        """srt_gather_band: memory rows `rows` of PathTracer `src`'s framebuffer into this one's (device to device)."""
+        self._ck(self.L.srt_gather_band(self._h, src._h, int(rows[0]), int(rows[1])))
 
     def device_framebuffer_ptr(self):
         p = C.c_void_p()

@@ -122,7 +122,7 @@ struct srt_context {
     bool order_stale = true;              // scene / camera changed since the costs were recorded
     bool estimate_stale = true;           // the scene changed since the order was last estimated on the device
     bool order_disabled = false;          // buffers for the feedback could not be allocated
-    hipEvent_t ev_cost = nullptr, ev_order = nullptr;
+    hipEvent_t ev_cost = nullptr, ev_order = nullptr, ev_gather = nullptr;
 
     srt_environment env;
     HostCamera camera;
@@ -270,6 +270,7 @@ int srt_destroy(srt_context* ctx) {
     if (ctx->h_wg_order) (void)hipHostFree(ctx->h_wg_order);
     if (ctx->ev_cost) (void)hipEventDestroy(ctx->ev_cost);
     if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
+    if (ctx->ev_gather) (void)hipEventDestroy(ctx->ev_gather);
     if (ctx->d_tile_masks) (void)hipFree(ctx->d_tile_masks);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
@@ -870,6 +871,30 @@ int srt_read_accumulator(srt_context* ctx, float* dst_rgba) {
     SRT_HIP(ctx, hipSetDevice(ctx->device));
     SRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SRT_HIP(ctx, hipMemcpy(dst_rgba, ctx->d_acc, (size_t)ctx->width * ctx->height * sizeof(float4), hipMemcpyDeviceToHost));
+    return SRT_OK;
+}
+
+int srt_gather_band(srt_context* dst, srt_context* src, int row_begin, int row_end) {
+    if (!dst || !src) return SRT_ERR_INVALID_ARG;
+    if (dst->width != src->width || dst->height != src->height)
+        return fail(dst, SRT_ERR_INVALID_ARG, "srt_gather_band: %dx%d into %dx%d", src->width, src->height, dst->width, dst->height);
+    if (row_begin < 0 || row_end > src->height || row_begin >= row_end)
+        return fail(dst, SRT_ERR_INVALID_ARG, "srt_gather_band: bad rows [%d,%d)", row_begin, row_end);
+    if (dst == src) return SRT_OK;
+    const size_t rowb = (size_t)src->width * 4, off = (size_t)row_begin * rowb, bytes = (size_t)(row_end - row_begin) * rowb;
+    SRT_HIP(dst, hipSetDevice(src->device));
+    if (src->device != dst->device) {
+        // direct xGMI path where the topology offers it; without peer access the runtime stages the copy
+        const hipError_t pe = hipDeviceEnablePeerAccess(dst->device, 0);
+        if (pe != hipSuccess) (void)hipGetLastError();  // already enabled, or not available: both fine
+        SRT_HIP(dst, hipMemcpyPeerAsync((char*)dst->d_fb + off, dst->device, (const char*)src->d_fb + off, src->device, bytes, src->stream));
+    } else {
+        SRT_HIP(dst, hipMemcpyAsync((char*)dst->d_fb + off, (const char*)src->d_fb + off, bytes, hipMemcpyDeviceToDevice, src->stream));
+    }
+    if (!src->ev_gather) SRT_HIP(dst, hipEventCreateWithFlags(&src->ev_gather, hipEventDisableTiming));
+    SRT_HIP(dst, hipEventRecord(src->ev_gather, src->stream));
+    SRT_HIP(dst, hipSetDevice(dst->device));
+    SRT_HIP(dst, hipStreamWaitEvent(dst->stream, src->ev_gather, 0));
     return SRT_OK;
 }
 

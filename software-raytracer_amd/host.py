@@ -22,6 +22,8 @@ EXPORTS = [
     "srt_host_renderer_invalidate", "srt_host_renderer_mode", "srt_host_renderer_pick", "srt_host_renderer_render_frame", "srt_host_renderer_render_samples",
     "srt_host_renderer_accumulation_frames", "srt_host_renderer_wait", "srt_host_renderer_read_framebuffer",
     "srt_host_renderer_read_accumulator", "srt_host_renderer_stats", "srt_host_renderer_handle",
+    "srt_host_multi_create", "srt_host_multi_destroy", "srt_host_multi_set_scene", "srt_host_multi_configure",
+    "srt_host_multi_render_samples", "srt_host_multi_read_framebuffer", "srt_host_multi_band", "srt_host_multi_stats",
 ]
 
 _lib = None
@@ -92,6 +94,16 @@ def load_library():
     L.srt_host_renderer_read_accumulator.argtypes = [vp, C.POINTER(C.c_float)]
     L.srt_host_renderer_stats.argtypes = [vp, C.POINTER(Stats)]
     L.srt_host_renderer_handle.argtypes = [vp]
+    L.srt_host_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int]
+    L.srt_host_multi_create.restype = vp
+    L.srt_host_multi_destroy.argtypes = [vp]
+    L.srt_host_multi_destroy.restype = None
+    L.srt_host_multi_set_scene.argtypes = [vp, vp]
+    L.srt_host_multi_configure.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_uint32]
+    L.srt_host_multi_render_samples.argtypes = [vp, C.c_uint32, C.c_int]
+    L.srt_host_multi_read_framebuffer.argtypes = [vp, vp, C.c_size_t]
+    L.srt_host_multi_band.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.srt_host_multi_stats.argtypes = [vp, C.POINTER(Stats), C.c_int]
     L.srt_host_renderer_handle.restype = vp
     _lib = L
     return L
@@ -274,3 +286,58 @@ class Renderer:
 
     def handle(self):
         return self.L.srt_host_renderer_handle(self._h)
+
+
+class MultiRenderer:
+    """MultiGpuRenderer (host/renderer.hpp): one frame over several devices of one node in ONE process — equal
+    memory-row bands, one context and stream per device, joined by srt_gather_band into the first device's
+    framebuffer.  A device may be listed several times (how it is tested on a one-GPU box)."""
+
+    def __init__(self, devices, width, height):
+        self.L = load_library()
+        self.width, self.height, self.n = width, height, len(devices)
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self._h = self.L.srt_host_multi_create(arr, len(devices), width, height)
+        if not self._h:
+            raise RuntimeError(self.L.srt_host_last_error().decode())
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError("host multi-renderer error %d: %s" % (rc, self.L.srt_host_last_error().decode()))
+
+    def close(self):
+        if self._h:
+            self.L.srt_host_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_scene(self, scene):
+        self._ck(self.L.srt_host_multi_set_scene(self._h, scene._h))
+
+    def configure(self, position=(0, 0, 0), basis9=(1, 0, 0, 0, 1, 0, 0, 0, 1), fov=55, max_bounces=2, seed=0):
+        p = (C.c_float * 3)(*[float(x) for x in position])
+        b = (C.c_float * 9)(*[float(x) for x in basis9])
+        self._ck(self.L.srt_host_multi_configure(self._h, p, b, int(fov), int(max_bounces), seed))
+
+    def render_samples(self, count, count_rays=False):
+        self._ck(self.L.srt_host_multi_render_samples(self._h, count, 1 if count_rays else 0))
+
+    def framebuffer(self):
+        out = np.empty((self.height, self.width), dtype=np.uint32)
+        self._ck(self.L.srt_host_multi_read_framebuffer(self._h, out.ctypes.data_as(C.c_void_p), self.width * 4))
+        return out
+
+    def band(self, i):
+        b, e = C.c_int(), C.c_int()
+        self._ck(self.L.srt_host_multi_band(self._h, int(i), C.byref(b), C.byref(e)))
+        return b.value, e.value
+
+    def stats(self):
+        arr = (Stats * self.n)()
+        self._ck(self.L.srt_host_multi_stats(self._h, arr, self.n))
+        return list(arr)

@@ -205,4 +205,43 @@ int srt_host_renderer_read_accumulator(srt_host_renderer* h, float* dst) {
 int srt_host_renderer_stats(srt_host_renderer* h, srt_stats* out) { SRT_HOST_TRY(h, *out = h->r->Stats()) }
 void* srt_host_renderer_handle(srt_host_renderer* h) { return h->r->handle(); }
 
+// ---- MultiGpuRenderer -----------------------------------------------------------------
+struct srt_host_multi {
+    MultiGpuRenderer* r = nullptr;
+};
+srt_host_multi* srt_host_multi_create(const int* devices, int n, int width, int height) {
+    try {
+        srt_host_multi* h = new srt_host_multi();
+        h->r = new MultiGpuRenderer(std::vector<int>(devices, devices + n), width, height);
+        return h;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+void srt_host_multi_destroy(srt_host_multi* h) {
+    if (h) {
+        delete h->r;
+        delete h;
+    }
+}
+int srt_host_multi_set_scene(srt_host_multi* h, srt_host_scene* s) { SRT_HOST_TRY(h, h->r->SetScene(s->scene)) }
+int srt_host_multi_configure(srt_host_multi* h, const float* pos, const float* right_up_forward, int fov, int max_bounces, uint32_t seed) {
+    Transform t;
+    t.position = Vec3(pos[0], pos[1], pos[2]);
+    t.right = Vec3(right_up_forward[0], right_up_forward[1], right_up_forward[2]);
+    t.up = Vec3(right_up_forward[3], right_up_forward[4], right_up_forward[5]);
+    t.forward = Vec3(right_up_forward[6], right_up_forward[7], right_up_forward[8]);
+    SRT_HOST_TRY(h, h->r->Configure(t, fov, max_bounces, seed))
+}
+int srt_host_multi_render_samples(srt_host_multi* h, uint32_t count, int count_rays) { SRT_HOST_TRY(h, h->r->RenderSamples(count, count_rays != 0)) }
+int srt_host_multi_read_framebuffer(srt_host_multi* h, void* dst, size_t pitch) { SRT_HOST_TRY(h, h->r->ReadFramebuffer(dst, pitch)) }
+int srt_host_multi_band(srt_host_multi* h, int i, int* begin, int* end) { SRT_HOST_TRY(h, h->r->Band((size_t)i, begin, end)) }
+int srt_host_multi_stats(srt_host_multi* h, srt_stats* out, int n) {
+    SRT_HOST_TRY(h, {
+        std::vector<srt_stats> st = h->r->Stats();
+        for (int i = 0; i < n && i < (int)st.size(); ++i) out[i] = st[(size_t)i];
+    })
+}
+
 }  // extern "C"

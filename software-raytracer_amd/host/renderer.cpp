@@ -144,4 +144,84 @@ std::vector<float> PathTraceRenderer::ReadAccumulator() {
     return out;
 }
 
+// ---- MultiGpuRenderer -------------------------------------------------------------------
+MultiGpuRenderer::MultiGpuRenderer(const std::vector<int>& devices, int width, int height) : width_(width), height_(height) {
+    if (devices.empty() || (int)devices.size() > height) throw RendererError(SRT_ERR_INVALID_ARG, "MultiGpuRenderer: need 1 <= devices <= height");
+    try {
+        for (int d : devices) parts_.push_back(new PathTraceRenderer(d, width, height));
+        for (size_t i = 0; i < parts_.size(); ++i) {
+            int b, e;
+            Band(i, &b, &e);
+            parts_[i]->SetRowBand(b, e);
+        }
+    } catch (...) {
+        for (PathTraceRenderer* p : parts_) delete p;
+        throw;
+    }
+}
+
+MultiGpuRenderer::~MultiGpuRenderer() {
+    for (PathTraceRenderer* p : parts_) delete p;
+}
+
+void MultiGpuRenderer::Band(size_t i, int* begin, int* end) const {
+    const int n = (int)parts_.size(), q = height_ / n, r = height_ % n, k = (int)i;
+    *begin = k * q + (k < r ? k : r);
+    *end = *begin + q + (k < r ? 1 : 0);
+}
+
+void MultiGpuRenderer::SetScene(const Scene& scene) {
+    for (PathTraceRenderer* p : parts_) p->SetScene(scene);
+}
+
+void MultiGpuRenderer::SetEnvironment(const srt_environment& env) {
+    for (PathTraceRenderer* p : parts_) p->SetEnvironment(env);
+}
+
+void MultiGpuRenderer::Configure(const Transform& camera, int fov, int max_bounces, uint32_t seed) {
+    for (PathTraceRenderer* p : parts_) {
+        p->camera = camera;
+        p->FOV = fov;
+        p->MAXBOUNCES = max_bounces;
+        p->seed = seed;
+        p->Invalidate();
+    }
+}
+
+void MultiGpuRenderer::Invalidate() {
+    for (PathTraceRenderer* p : parts_) p->Invalidate();
+}
+
+void MultiGpuRenderer::RenderSamples(uint32_t count, bool count_rays) {
+    for (PathTraceRenderer* p : parts_) p->RenderSamples(count, count_rays);  // asynchronous: one stream per part
+    for (size_t i = 1; i < parts_.size(); ++i) {                              // the one gather
+        int b, e;
+        Band(i, &b, &e);
+        int rc = srt_gather_band(parts_[0]->handle(), parts_[i]->handle(), b, e);
+        if (rc != SRT_OK) {
+            const char* msg = srt_last_error(parts_[0]->handle());
+            throw RendererError(rc, std::string("srt_gather_band: ") + (msg ? msg : "?"));
+        }
+    }
+}
+
+void MultiGpuRenderer::Wait() {
+    for (size_t i = parts_.size(); i-- > 0;) parts_[i]->Wait();  // part 0 last: its stream waits for every band
+}
+
+void MultiGpuRenderer::ReadFramebuffer(void* pixels, size_t pitch_bytes) {
+    Wait();
+    int rc = srt_read_framebuffer(parts_[0]->handle(), pixels, pitch_bytes, 0, height_);
+    if (rc != SRT_OK) {
+        const char* msg = srt_last_error(parts_[0]->handle());
+        throw RendererError(rc, std::string("srt_read_framebuffer: ") + (msg ? msg : "?"));
+    }
+}
+
+std::vector<srt_stats> MultiGpuRenderer::Stats() {
+    std::vector<srt_stats> out;
+    for (PathTraceRenderer* p : parts_) out.push_back(p->Stats());
+    return out;
+}
+
 }  // namespace srt_host

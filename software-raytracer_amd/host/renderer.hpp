@@ -120,4 +120,41 @@ class PathTraceRenderer {
     uint32_t next_clean_sample_ = 1;
 };
 
+// One frame over N GPUs of one node, in ONE process: the reference's split of a frame over 16 worker threads
+// (disjoint column stripes of one surface, Raytracer.cpp:330-342) becomes disjoint bands of MEMORY rows, one
+// PathTraceRenderer (= one srt_context, one stream) per device.  Pixels share nothing — the random stream is keyed
+// by the absolute pixel — so the bands render with no exchange, and ONE gather joins them: every band is copied,
+// device to device, into the first device's framebuffer (srt_gather_band: peer copies over xGMI, each peer on its
+// own link to the root).  Rank-order concatenation of memory-row bands IS the final image.  The same device may be
+// listed several times (N contexts on N streams of one GPU): that is how the class is tested on a one-GPU box.
+class MultiGpuRenderer {
+   public:
+    MultiGpuRenderer(const std::vector<int>& devices, int width, int height);
+    ~MultiGpuRenderer();
+    MultiGpuRenderer(const MultiGpuRenderer&) = delete;
+    MultiGpuRenderer& operator=(const MultiGpuRenderer&) = delete;
+
+    size_t size() const { return parts_.size(); }
+    PathTraceRenderer& part(size_t i) { return *parts_[i]; }
+    // memory-row band of part i: equal bands, the first height % N parts take one more row
+    void Band(size_t i, int* begin, int* end) const;
+
+    void SetScene(const Scene& scene);  // replicated: every device gets its own copy (a few KB; meshes: a few MB)
+    void SetEnvironment(const srt_environment& env);
+    // camera and settings of every part (the reference's globals; see PathTraceRenderer)
+    void Configure(const Transform& camera, int fov, int max_bounces, uint32_t seed);
+    void Invalidate();
+    // `count` further samples on every band (all launches are enqueued before anything is waited for), then the
+    // gather into part 0; after Wait() part 0 holds the whole frame
+    void RenderSamples(uint32_t count, bool count_rays = false);
+    void Wait();
+    void ReadFramebuffer(void* pixels, size_t pitch_bytes);  // the whole frame, from part 0
+    // per part: kernel time of its last launch and its ray count (imbalance of static bands, SURVEY §8e caveat)
+    std::vector<srt_stats> Stats();
+
+   private:
+    std::vector<PathTraceRenderer*> parts_;
+    int width_, height_;
+};
+
 }  // namespace srt_host

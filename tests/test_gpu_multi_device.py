@@ -1,0 +1,72 @@
+"""The native (C++ / C-ABI, no Python in the data path) multi-GPU row-stripe renderer of SURVEY §8e:
+host/renderer.hpp MultiGpuRenderer = one srt_context and stream per device, equal memory-row bands, joined by
+srt_gather_band (device-to-device copies into the first device's framebuffer).  On a one-GPU box the N contexts
+all live on device 0 — the control flow, the band arithmetic and the stream ordering are the same."""
+import ctypes as C
+import subprocess
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, scene_path
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,n_parts,w,h,spp", [("Scene_indirect", 3, 200, 113, 3), ("Scene1", 8, 1920, 1080, 4), ("Scene3", 5, 333, 97, 20)])
+def test_multi_renderer_equals_single_device_and_oracle(srt, oracle, name, n_parts, w, h, spp):
+    scene = srt.host.Scene(scene_path(name))
+    m = srt.host.MultiRenderer([0] * n_parts, w, h)
+    m.set_scene(scene)
+    m.configure(fov=55, max_bounces=6, seed=3)
+    bands = [m.band(i) for i in range(n_parts)]
+    assert bands[0][0] == 0 and bands[-1][1] == h and all(bands[i][1] == bands[i + 1][0] for i in range(n_parts - 1))
+    assert max(b - a for a, b in bands) - min(b - a for a, b in bands) <= 1  # equal bands (first h % N one row taller)
+    m.render_samples(spp, count_rays=True)
+    fb = m.framebuffer()
+    st = m.stats()
+    assert sum(s.path_samples for s in st) == w * h * spp
+    # single device, same settings
+    objs, n = scene.objects_copy()
+    pt = srt.PathTracer(w, h)
+    pt.set_scene(objs, n)
+    pt.set_camera(srt.default_camera())
+    pt.render(spp=spp, bounces=6, seed=3, count_rays=True)
+    assert np.array_equal(fb, pt.framebuffer())
+    assert sum(s.rays for s in st) == pt.stats().rays
+    if w * h * spp <= 2_000_000:
+        ofb, _, _ = oracle.render(C.cast(objs, C.POINTER(oracle.Object)), n, oracle.default_environment(), oracle.default_camera(), w, h,
+                                  spp=spp, bounces=6, seed=3)
+        assert np.array_equal(fb, ofb)
+    # a second batch continues the running means on every band (resume), like one device
+    m.render_samples(2)
+    pt.render(spp=2, bounces=6, seed=3, first_sample=spp + 1, reset=False)
+    assert np.array_equal(m.framebuffer(), pt.framebuffer())
+    m.close()
+    pt.close()
+
+
+def test_gather_band_argument_checks(srt):
+    a, b, c = srt.PathTracer(64, 32), srt.PathTracer(64, 32), srt.PathTracer(32, 32)
+    with pytest.raises(srt.SrtError):
+        a.gather_band_from(c, (0, 8))   # different size
+    with pytest.raises(srt.SrtError):
+        a.gather_band_from(b, (8, 8))   # empty band
+    with pytest.raises(srt.SrtError):
+        a.gather_band_from(b, (0, 33))  # beyond the frame
+    a.gather_band_from(a, (0, 32))      # self: nothing to do
+    for t in (a, b, c):
+        t.close()
+
+
+def test_cli_devices_flag(tmp_path):
+    """srt_render --devices 0,0,0 writes the same PPM as the single-device run."""
+    exe = os.path.join(ROOT, "software-raytracer_amd", "srt_render")
+    one, three = tmp_path / "one.ppm", tmp_path / "three.ppm"
+    common = [exe, "--scene", scene_path("Scene2"), "--width", "160", "--height", "90", "--spp", "4", "--bounces", "4"]
+    r1 = subprocess.run(common + ["--out", str(one)], capture_output=True, text=True, timeout=120)
+    r3 = subprocess.run(common + ["--devices", "0,0,0", "--out", str(three)], capture_output=True, text=True, timeout=120)
+    assert r1.returncode == 0 and r3.returncode == 0, r1.stderr + r3.stderr
+    assert one.read_bytes() == three.read_bytes()
+    assert "over 3 parts" in r3.stderr
