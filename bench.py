@@ -302,7 +302,16 @@ def main():
 
     # rays per sample (deterministic): one extra, untimed launch with the counter on
     step(count_rays=True)
-    rays = pt.stats().rays
+    st_last = pt.stats()
+    rays = st_last.rays
+    # sample-chunked launch (srt_stats.sample_chunks > 1): the colours of every TRACED sample go through HBM once (16 B
+    # written by pathtrace_kernel, 16 B read by fold_kernel).  Traced pixels = pixels whose primary ray hits something:
+    # a 1-spp / 1-bounce launch casts exactly one extra ray for each of them.
+    chunks = int(st_last.sample_chunks)
+    traced_samples = 0
+    if chunks > 1:
+        pt.render(spp=1, bounces=1, seed=SEED, first_sample=1, reset=True, rows=(rb, re), count_rays=True)
+        traced_samples = (pt.stats().rays - W * (re - rb)) * spp
     local_samples = W * (re - rb) * spp
     rbar_local = rays / local_samples
 
@@ -342,8 +351,7 @@ def main():
         f_sample = algorithmic_laneops_per_sample(rbar_local, n_sph, n_box, node_items, tri_tests)
         achieved_valu = f_sample * local_samples / (k_ms * 1e-3)
         abytes = algorithmic_bytes(W, re - rb, n_obj, resume=False)
-        if counters.get("chunked"):  # sample-chunked launch: + 16 B written and 16 B read per traced sample (the fold's stream)
-            abytes += int(counters["traced_samples_per_launch"]) * 32
+        abytes += 32 * traced_samples  # sample-chunked launch: + 16 B written and 16 B read per traced sample (the fold's stream)
         achieved_gbs = abytes / (k_ms * 1e-3) / 1e9
         if n_tri and not mesh_counts:
             kind = "UNCOUNTED: no profiles/mesh_counts.json entry for this workload; the BVH work is missing from `achieved`"
@@ -393,7 +401,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved_valu / VALU_PEAK_LANEOPS,
                 "traffic": counters.get("hbm_bytes_per_launch"),
-                "kernel": "srt::pathtrace_kernel" + (" + srt::fold_kernel" if counters.get("chunked") else ""),
+                "kernel": "srt::pathtrace_kernel" + (" + srt::fold_kernel (%d sample chunks)" % chunks if chunks > 1 else ""),
                 "kernel_ms": k_ms,
                 "kernel_ms_source": "HIP events on the launch stream around the %d timed steps / %d" % (args.steps, args.steps)
                                     if world == 1 else "the library's event pair around the last timed launch",
@@ -415,7 +423,7 @@ def main():
                 "traffic": counters.get("hbm_bytes_per_launch"),
                 "algorithmic_bytes_per_launch": abytes,
                 "note": "compulsory bytes only (20 B/pixel + scene%s); not the limiting resource" %
-                        (" + 32 B per traced sample of the chunked launch's sample buffer" if counters.get("chunked") else ""),
+                        (" + 32 B per traced sample of the chunked launch's sample buffer" if chunks > 1 else ""),
             },
             "per_rank": [{"kernel_ms": p[0], "rays_per_sample": p[1] / p[2], "rows": list(bands[i] if not share else (rb, re))}
                          for i, p in enumerate(per_rank)],

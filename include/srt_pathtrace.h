@@ -152,6 +152,9 @@ typedef struct srt_stats {
     uint64_t rays;          /* GetClosestObject calls (primary counted once per sample) */
     uint64_t path_samples;  /* W_band * H_band * sample_count of the last render */
     float kernel_ms;        /* HIP-event time of the last render's kernel(s) on its stream */
+    uint32_t sample_chunks; /* 1: one kernel traced and folded every sample; n > 1: the samples of a tile were split
+                               over n workgroups that stored the colours, and a second, streaming kernel folded
+                               them in order (16 B written + 16 B read per traced sample on top of the 20 B/pixel) */
 } srt_stats;
 
 typedef struct srt_context srt_context;

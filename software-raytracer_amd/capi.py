@@ -100,7 +100,7 @@ class RenderParams(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("path_samples", C.c_uint64), ("kernel_ms", C.c_float)]
+    _fields_ = [("rays", C.c_uint64), ("path_samples", C.c_uint64), ("kernel_ms", C.c_float), ("sample_chunks", C.c_uint32)]
 
 
 def lib_path():

@@ -129,6 +129,7 @@ struct srt_context {
     srt_stats stats{};
     bool stats_pending = false;
     uint64_t pending_samples = 0;
+    uint32_t pending_chunks = 1;
     bool count_rays = false;
     int lds_limit_bytes = 64 * 1024;
     int cu_count = 256;
@@ -752,6 +753,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     ctx->launched = true;
     ctx->stats_pending = true;
     ctx->pending_samples = (uint64_t)W * (uint64_t)K.rows * p->sample_count;
+    ctx->pending_chunks = (uint32_t)chunks;
     return SRT_OK;
 }
 
@@ -845,6 +847,7 @@ int srt_get_stats(srt_context* ctx, srt_stats* out) {
         SRT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
         ctx->stats.kernel_ms = ms;
         ctx->stats.path_samples = ctx->pending_samples;
+        ctx->stats.sample_chunks = ctx->pending_chunks;
         ctx->stats.rays = 0;
         if (ctx->count_rays) {
             unsigned long long r = 0;

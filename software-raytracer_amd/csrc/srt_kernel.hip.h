@@ -544,8 +544,10 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                     push(sel, (unsigned)lane << 26, qn, nN, MESH_QN);
                     __builtin_amdgcn_wave_barrier();
                     while (!overflow && (nN > 0 || nL > 0)) {
-                        // ---- one round pops items of ONE queue (serving both in one round was tried: one round trip fewer
-                        // per level, but the two code paths together spill 30 registers and the launch got 45 % slower).
+                        // ---- one round pops items of ONE queue.  (Tried and measured slower on config 4: serving both queues in
+                        // every round — rounds per phase 11.0 -> 9.9, but every round then runs both code paths, +8 % time; a
+                        // leaf queue of single triangles, one per lane — fewer leaf rounds, but more queue traffic and the
+                        // node rounds get throttled by the leaf queue's room, +7 %.)
                         // Nodes first, until 64 leaves wait: a node's 8 children are spread over 8 / 4 / 2 / 1 lanes so that the
                         // wave stays full however few items wait; a leaf gets four lanes, one triangle each — one memory
                         // round trip per leaf round instead of one per triangle.

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Regenerates profiles/<round>/ and profiles/{counters,mesh_counts}.json on the GPU box.
+
+usage (through gpurun, from the repo root):  python3 tools/profile_round.py r02 [--only c2,c4,...]
+
+For every workload below:
+  profiles/<round>/bench_<name>.json         the bench.py line (roofline, roofline_hbm, cpu_baseline where it applies)
+  profiles/<round>/kernel_stats_<name>.csv   rocprofv3 --kernel-trace --stats of the same bench.py command
+  profiles/counters.json[workload_key]       PMC counters per FULL launch of the workload, one counter group per pass
+                                             (tools/pmc_collect.py: never together with a trace domain; FETCH_SIZE and
+                                             WRITE_SIZE in passes of their own), summed over the launch's kernels
+                                             (pathtrace_kernel + fold_kernel for sample-chunked launches):
+                                             SQ_INSTS_VALU, hbm_bytes_per_launch = FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024
+                                             (gfx950: FETCH_SIZE reports half of a wide streaming read, MI355X_MICROARCH.md)
+  profiles/mesh_counts.json[workload_key]    mesh workloads: BVH node items and triangle tests per path-sample, counted by
+                                             the development library's STATS=1 counters (tests/mesh_stats.py)
+bench.py reads the two json files to fill roofline.traffic / measured_valu_issue_frac / the counted mesh work; the
+final bench lines are therefore written AFTER the counters.
+"""
+import glob
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+WORKLOADS = [  # name, bench.py arguments, mesh tessellation
+    ("c2", [], 0),
+    ("c3_rank4of8", ["--config", "3", "--rank", "4/8"], 0),
+    ("c3_rank7of8", ["--config", "3", "--rank", "7/8"], 0),
+    ("c4", ["--config", "4"], 224),
+    ("c5_rank4of8", ["--config", "5", "--rank", "4/8", "--steps", "3", "--warmup", "1"], 224),
+    ("scene_indirect", ["--scene", "Scene_indirect"], 0),
+]
+
+
+def run(cmd, **kw):
+    return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, **kw)
+
+
+def main():
+    rnd = sys.argv[1]
+    only = None
+    if len(sys.argv) > 3 and sys.argv[2] == "--only":
+        only = set(sys.argv[3].split(","))
+    out = os.path.join(ROOT, "profiles", rnd)
+    scratch = os.path.join(ROOT, "gpurun_out", "profile_" + rnd)
+    os.makedirs(out, exist_ok=True)
+    os.makedirs(scratch, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    cpath, mpath = os.path.join(ROOT, "profiles", "counters.json"), os.path.join(ROOT, "profiles", "mesh_counts.json")
+    counters = json.load(open(cpath)) if os.path.exists(cpath) else {}
+    mesh_counts = json.load(open(mpath)) if os.path.exists(mpath) else {}
+    bench = [sys.executable, os.path.join(ROOT, "bench.py")]
+    for name, args, mesh in WORKLOADS:
+        if only and name not in only:
+            continue
+        steps = [] if "--steps" in args else ["--steps", "10", "--warmup", "3"]
+        # 1. a first bench line: the workload key, rays per sample, samples per launch
+        r = run(bench + args + steps + ["--no-cpu-baseline"], cwd=ROOT)
+        if r.returncode != 0:
+            print(name, "bench failed:", r.stderr[-500:])
+            continue
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        key = line["config"]["workload_key"]
+        print(name, key, "%.4g samples/s" % line["value"], flush=True)
+        # 2. kernel trace + stats of the same command
+        d = os.path.join(scratch, "trace_" + name)
+        r = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", os.path.join(ROOT, "bench.py")] + args + steps +
+                ["--no-cpu-baseline"], cwd="/tmp", env=env, timeout=900)
+        st = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)
+        if st:
+            open(os.path.join(out, "kernel_stats_%s.csv" % name), "w").write(open(st[0]).read())
+        # 3. counters, one group per pass
+        r = run([sys.executable, os.path.join(ROOT, "tools", "pmc_collect.py"), "profile_%s/pmc_%s" % (rnd, name), "--groups", "hbm_r,hbm_w,sq1,sq2", "--"] + args +
+                ["--steps", "3", "--warmup", "2"], cwd=ROOT, timeout=1500)
+        pj = os.path.join(scratch, "pmc_" + name, "pmc.json")
+        if os.path.exists(pj):
+            doc = json.load(open(pj))
+            tot = {}
+            for kname, k in doc["kernels"].items():
+                if "pathtrace_kernel" in kname or "fold_kernel" in kname:
+                    for c in ("SQ_INSTS_VALU", "hbm_bytes", "FETCH_SIZE", "WRITE_SIZE", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+                              "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_WAVES"):
+                        if c in k:
+                            tot[c] = tot.get(c, 0.0) + k[c]
+            entry = {"source": "profiles/%s (tools/profile_round.py -> tools/pmc_collect.py, rocprofv3 --pmc, mean per full launch, pathtrace_kernel + fold_kernel)" % rnd,
+                     "kernels": sorted(k for k in doc["kernels"] if "pathtrace_kernel" in k or "fold_kernel" in k)}
+            entry.update(tot)
+            if "hbm_bytes" in tot:
+                entry["hbm_bytes_per_launch"] = tot["hbm_bytes"]
+            if "GRBM_GUI_ACTIVE" in tot and "SQ_WAVE_CYCLES" in tot:
+                entry["waves_per_cu"] = tot["SQ_WAVE_CYCLES"] * 4 / (tot["GRBM_GUI_ACTIVE"] / 8 * 256)
+            counters[key] = entry
+            json.dump(counters, open(cpath, "w"), indent=1, sort_keys=True)
+            open(os.path.join(out, "pmc_%s.json" % name), "w").write(json.dumps(doc, indent=1))
+        else:
+            print(name, "pmc failed:", r.stdout[-300:], r.stderr[-300:])
+        # 4. mesh workloads: counted BVH work per path-sample (STATS=1 development library; per-sample figures do not
+        #    depend on the sample count, so 8 spp of the same frame and bounces are counted)
+        if mesh:
+            cfg = line["config"]
+            m = re.match(r".* (\d+)x(\d+) rows(\d+)-(\d+) spp(\d+) b(\d+)", key)
+            w, h, rb, re_, spp, b = (int(v) for v in m.groups())
+            r = run([sys.executable, os.path.join(ROOT, "tests", "mesh_stats.py"), "--mesh", str(mesh), "--spp", "8", "--bounces", str(b), "--width", str(w),
+                     "--height", str(h), "--rows", "%d,%d" % (rb, re_), "--json"], cwd=ROOT, timeout=600)
+            js = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if js:
+                ms = json.loads(js[-1])
+                samples = w * (re_ - rb) * 8
+                mesh_counts[key] = {"node_items_per_sample": ms["node items"] / samples, "triangle_tests_per_sample": 4.0 * ms["leaf items"] / samples,  # a leaf item runs four lanes, one triangle slot each
+                                    "mesh_rays_per_sample": ms["go lanes"] / samples, "mesh_phases": ms["mesh phases (waves)"],
+                                    "source": "tests/mesh_stats.py (development library, STATS=1 counters), %dx%d rows %d-%d, 8 spp, %d bounces" % (w, h, rb, re_, b)}
+                json.dump(mesh_counts, open(mpath, "w"), indent=1, sort_keys=True)
+            else:
+                print(name, "mesh_stats failed:", r.stdout[-300:], r.stderr[-300:])
+        # 5. the bench line that is committed (reads the counters written above; with the CPU baseline where it is cheap)
+        r = run(bench + args + steps, cwd=ROOT)
+        js = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if js:
+            open(os.path.join(out, "bench_%s.json" % name), "w").write(js[-1] + "\n")
+            d = json.loads(js[-1])
+            rf = d["roofline"]
+            print("   -> %.4g samples/s, kernel %.3f ms (cold %.3f), valu frac %.3f (%s), measured issue %s, hbm traffic %s vs algorithmic %d" %
+                  (d["value"] or 0, rf["kernel_ms"], rf["kernel_ms_cold_first_launch"] or 0, rf["frac"], rf["achieved_kind"].split(":")[0],
+                   rf["measured_valu_issue_frac"], rf["traffic"], d["roofline_hbm"]["algorithmic_bytes_per_launch"]), flush=True)
+        else:
+            print(name, "final bench failed:", r.stderr[-500:])
+
+
+if __name__ == "__main__":
+    main()
