@@ -172,8 +172,9 @@ struct Lds {
     __device__ __forceinline__ int order(int p) const { return __float_as_int(v[off_mat + 3 * p + 2].w); }
 };
 
-// sign(float3) component (Common.hpp:328-333): t != 0 ? t / abs(t) : 0
-__device__ __forceinline__ float sign1(float t) { return t != 0 ? t / fabsf(t) : 0.0f; }
+// sign(float3) component (Common.hpp:328-333): t != 0 ? t / abs(t) : 0.  For finite t != 0 the quotient is exactly +-1, for
+// +-inf and NaN it is NaN: copysign(1, t) + (t - t) has the same value in every case (t - t is +0 or NaN) without the divide.
+__device__ __forceinline__ float sign1(float t) { return t != 0 ? __builtin_copysignf(1.0f, t) + (t - t) : 0.0f; }
 // template max / min (Common.hpp:344-351)
 __device__ __forceinline__ float tmax(float a, float b) { return a > b ? a : b; }
 __device__ __forceinline__ float tmin(float a, float b) { return a < b ? a : b; }
