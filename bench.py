@@ -121,9 +121,11 @@ def main():
     ap.add_argument("--mesh", type=int, default=None, metavar="N", help="EXTENSION: replace Scene1's big ball by an N x N tessellation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the bounded CPU sample (16 spp at 1080p = about 20 s of CPU work)")
-    ap.add_argument("--balance", default="equal", choices=["equal", "cost"],
-                    help="row-stripe split for N > 1: equal bands + one dist.gather (north_star), or cost-balanced bands "
-                         "(opt-in: a probe + one calibration launch before the timed region, reported in the JSON)")
+    ap.add_argument("--balance", default="equal", choices=["equal", "probe", "cost"],
+                    help="row-stripe split for N > 1 (and for --rank): equal bands + one dist.gather (north_star); 'probe': bands of "
+                         "equal estimated cost from the library's device-side probe (srt_estimate_row_costs, ~0.1 ms, deterministic: "
+                         "no collective, no extra launch) + one padded dist.gather; 'cost': a 1-spp ray-count probe per 8 rows and one "
+                         "calibration launch with an all_gather (their cost is reported in the JSON; never inside the timed region)")
     ap.add_argument("--gather", default="padded", choices=["padded", "p2p"],
                     help="cost-balanced (unequal) bands only: one dist.gather of bands padded to the tallest, or one grouped isend/irecv")
     args = ap.parse_args()
@@ -206,7 +208,15 @@ def main():
 
     # ---- row stripes -----------------------------------------------------------------
     calibration = None
-    if share:
+    n_parts = share[1] if share else world
+    if n_parts > 1 and args.balance == "probe":
+        t_cal = time.perf_counter()
+        row_cost = pt.estimate_row_costs(bounces, SEED)
+        bands = stripes.partition_rows(H, n_parts, row_cost, align=8)
+        calibration = {"calibration_launches": 1, "calibration_ms": (time.perf_counter() - t_cal) * 1e3,
+                       "calibration": "srt_estimate_row_costs: one device-side probe of 1/16 of the pixels at one sample, same numbers on every rank"}
+        rb, re = bands[share[0] if share else rank]
+    elif share:
         bands = stripes.partition_rows(H, share[1])
         rb, re = bands[share[0]]
     elif world > 1 and args.balance == "cost":
@@ -389,7 +399,7 @@ def main():
                 "objects": {"spheres": n_sph, "boxes": n_box, "mesh_triangles": n_tri},
                 "partition": "single frame" if world == 1 and not share else
                              "row stripes in memory-row space, %s bands, one %s" % (
-                                 args.balance if not share else "equal",
+                                 args.balance,
                                  "dist.gather over RCCL" if gather_method == "gather" else "RCCL gather (%s)" % gather_method),
                 "bands": bands if not share else [[rb, re]],
                 "rays_per_sample": rbar,

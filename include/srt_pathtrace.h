@@ -224,6 +224,13 @@ int srt_write_accumulator(srt_context* ctx, const float* src_rgba);
  * width and height.  (Across PROCESSES the same gather is one RCCL collective:
  * software-raytracer_amd/stripes.py, bench.py --gpus N.) */
 int srt_gather_band(srt_context* dst, srt_context* src, int row_begin, int row_end);
+/* Relative cost of every MEMORY row of the frame for the current scene and camera (row_costs[height], arbitrary
+ * units), from a device-side probe: 1/16 of the pixels, one sample each, the same paths the renderer would trace
+ * (about 0.1 ms at 1080p).  Deterministic — every process of a multi-GPU job computes the same numbers, so the ranks
+ * can agree on cost-balanced row bands without talking to each other.  The reference's static split into 16 equal
+ * column stripes (Raytracer.cpp:330-342) leaves its workers idle behind the slowest one; equal ROW bands are worse
+ * (sky rows cost a tenth of floor rows).  Synchronous. */
+int srt_estimate_row_costs(srt_context* ctx, int max_bounces, uint32_t seed, float* row_costs);
 
 #ifdef __cplusplus
 }

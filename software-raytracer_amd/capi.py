@@ -24,7 +24,7 @@ EXPORTS = [
     "srt_set_scene", "srt_set_meshes", "srt_set_environment", "srt_environment_default", "srt_set_camera",
     "srt_set_stream", "srt_bind_output", "srt_device_framebuffer", "srt_device_accumulator",
     "srt_render", "srt_wait", "srt_poll", "srt_get_stats", "srt_pick", "srt_read_framebuffer",
-    "srt_read_accumulator", "srt_write_accumulator", "srt_gather_band",
+    "srt_read_accumulator", "srt_write_accumulator", "srt_gather_band", "srt_estimate_row_costs",
 ]
 
 
@@ -170,6 +170,7 @@ def load_library():
     L.srt_read_accumulator.argtypes = [ctx, C.POINTER(C.c_float)]
     L.srt_write_accumulator.argtypes = [ctx, C.POINTER(C.c_float)]
     L.srt_gather_band.argtypes = [ctx, ctx, C.c_int, C.c_int]
+    L.srt_estimate_row_costs.argtypes = [ctx, C.c_int, C.c_uint32, C.POINTER(C.c_float)]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name != "srt_last_error":
@@ -299,6 +300,12 @@ class PathTracer:
         a = np.ascontiguousarray(arr, dtype=np.float32)
         assert a.shape == (self.height, self.width, 4)
         self._ck(self.L.srt_write_accumulator(self._h, a.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def estimate_row_costs(self, bounces, seed=0):
+        """srt_estimate_row_costs: relative cost per memory row (list of floats) from the device-side probe."""
+        out = (C.c_float * self.height)()
+        self._ck(self.L.srt_estimate_row_costs(self._h, int(bounces), int(seed), out))
+        return list(out)
 
     def gather_band_from(self, src, rows):
         """srt_gather_band: memory rows `rows` of PathTracer `src`'s framebuffer into this one's (device to device)."""

@@ -691,9 +691,9 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             const size_t image_bytes = (size_t)(K.scene_vec4 > 0 ? K.scene_vec4 : 1) * sizeof(float4);
             const size_t est_lds = (ctx->pick_in_lds[img] ? image_bytes : 0) + srt::WAVE_SCRATCH_BYTES + srt::MESH_WAVE_BYTES;
             if (ctx->pick_in_lds[img])
-                hipLaunchKernelGGL(srt::block_cost_kernel<true>, dim3((unsigned)((nwg + 3) / 4)), dim3(64), est_lds, ctx->stream, K, ctx->d_wg_est, (int)grid.x, (int)nwg);
+                hipLaunchKernelGGL(srt::block_cost_kernel<true>, dim3((unsigned)((nwg + 3) / 4)), dim3(64), est_lds, ctx->stream, K, ctx->d_wg_est, (int)grid.x, (int)nwg, (uint32_t*)nullptr);
             else
-                hipLaunchKernelGGL(srt::block_cost_kernel<false>, dim3((unsigned)((nwg + 3) / 4)), dim3(64), est_lds, ctx->stream, K, ctx->d_wg_est, (int)grid.x, (int)nwg);
+                hipLaunchKernelGGL(srt::block_cost_kernel<false>, dim3((unsigned)((nwg + 3) / 4)), dim3(64), est_lds, ctx->stream, K, ctx->d_wg_est, (int)grid.x, (int)nwg, (uint32_t*)nullptr);
             hipLaunchKernelGGL(srt::smooth_cost_kernel, dim3((unsigned)((nwg + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_wg_est, ctx->d_wg_est + nwg, (int)nwg, (int)grid.x);
             hipLaunchKernelGGL(srt::order_sort_kernel, dim3(1), dim3(srt::ORDER_SORT_THREADS), 0, ctx->stream, ctx->d_wg_est + nwg, ctx->d_wg_order, (int)nwg);
             if (hipGetLastError() == hipSuccess) {
@@ -877,6 +877,46 @@ int srt_read_accumulator(srt_context* ctx, float* dst_rgba) {
     SRT_HIP(ctx, hipSetDevice(ctx->device));
     SRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SRT_HIP(ctx, hipMemcpy(dst_rgba, ctx->d_acc, (size_t)ctx->width * ctx->height * sizeof(float4), hipMemcpyDeviceToHost));
+    return SRT_OK;
+}
+
+int srt_estimate_row_costs(srt_context* ctx, int max_bounces, uint32_t seed, float* row_costs) {
+    if (!ctx || !row_costs) return SRT_ERR_INVALID_ARG;
+    if (!ctx->scene_set) return fail(ctx, SRT_ERR_STATE, "srt_estimate_row_costs: srt_set_scene has not been called");
+    if (!ctx->camera.set) return fail(ctx, SRT_ERR_STATE, "srt_estimate_row_costs: srt_set_camera has not been called");
+    if (max_bounces < 0) return fail(ctx, SRT_ERR_INVALID_ARG, "srt_estimate_row_costs: max_bounces must be >= 0");
+    SRT_HIP(ctx, hipSetDevice(ctx->device));
+    const int W = ctx->width, H = ctx->height;
+    srt_render_params p{};
+    p.row_begin = 0, p.row_end = H, p.first_sample = 1, p.sample_count = 1, p.max_bounces = max_bounces, p.seed = seed;
+    srt::KernelParams K;
+    size_t lds_bytes = 0;
+    int use = 0, img = 0;
+    fill_kernel_params(ctx, &p, K, lds_bytes, use, img);
+    K.tile_h = srt::TILE_H;
+    const int bx = (W + srt::WG_W - 1) / srt::WG_W, by = (H + srt::WG_H - 1) / srt::WG_H, n = bx * by;
+    uint32_t* d = nullptr;
+    SRT_HIP(ctx, hipMalloc((void**)&d, (size_t)2 * n * sizeof(uint32_t)));
+    const size_t image_bytes = (size_t)(K.scene_vec4 > 0 ? K.scene_vec4 : 1) * sizeof(float4);
+    const size_t est_lds = (ctx->pick_in_lds[img] ? image_bytes : 0) + srt::WAVE_SCRATCH_BYTES + srt::MESH_WAVE_BYTES;
+    if (ctx->pick_in_lds[img])
+        hipLaunchKernelGGL(srt::block_cost_kernel<true>, dim3((unsigned)((n + 3) / 4)), dim3(64), est_lds, ctx->stream, K, d, bx, n, d + n);
+    else
+        hipLaunchKernelGGL(srt::block_cost_kernel<false>, dim3((unsigned)((n + 3) / 4)), dim3(64), est_lds, ctx->stream, K, d, bx, n, d + n);
+    std::vector<uint32_t> h((size_t)n);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d + n, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(ctx, SRT_ERR_HIP, "srt_estimate_row_costs: %s", hipGetErrorString(e));
+    // a block covers WG_H scene rows; its cost is spread evenly over them; memory row m = scene row H - 1 - m
+    for (int m = 0; m < H; ++m) row_costs[m] = 0.0f;
+    for (int j = 0; j < by; ++j) {
+        double sum = 0;
+        for (int i = 0; i < bx; ++i) sum += (double)h[(size_t)j * bx + i];
+        const int y0 = j * srt::WG_H, y1 = y0 + srt::WG_H < H ? y0 + srt::WG_H : H;
+        for (int y = y0; y < y1; ++y) row_costs[H - 1 - y] = (float)(sum / (double)(y1 - y0));
+    }
     return SRT_OK;
 }
 

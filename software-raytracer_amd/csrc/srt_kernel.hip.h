@@ -1365,7 +1365,7 @@ __global__ void __launch_bounds__(64) pick_kernel(const KernelParams P, int px, 
 // learned order).  Any order gives the same image.
 constexpr int ORDER_BUCKETS = 16, ORDER_SORT_THREADS = 512;
 template <bool SCENE_LDS>
-__global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, uint32_t* cost, int blocks_x, int n_blocks) {
+__global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, uint32_t* cost, int blocks_x, int n_blocks, uint32_t* balance_cost) {
     extern __shared__ float4 lds_scene[];
     if constexpr (SCENE_LDS) {
         for (int i = threadIdx.x; i < P.scene_vec4; i += 64) lds_scene[i] = P.scene[i];
@@ -1390,6 +1390,11 @@ __global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, ui
     Hit h = closest_hit<true>(S, P, v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]), sray, in_range, 1, deferred SRT_PROF_ARG);
     const int first_mesh_prim = S.nsT + S.nb;
     unsigned c = in_range ? 1u : 0u;
+    // second estimate, for splitting a frame over GPUs (srt_estimate_row_costs): TIME rather than rays, in 1/64 of the time
+    // of one bounce ray — a sample of a pixel that traces nothing costs about 0.11 of that (the running mean is still
+    // evaluated sample by sample), the primary ray is traced once per pixel whatever the sample count (free), a bounce ray
+    // that ends on a mesh about six times an analytic one (fitted to measured bands of configs 3 and 5)
+    unsigned cb = in_range ? 7u : 0u;
     bool alive = in_range && h.prim >= 0 && P.max_bounces > 0 && !(P.flags & 4u);
     uint32_t rng = srt_rng_key(P.seed, (uint32_t)(x + y * P.width), P.first_sample);
     float spec = 0.0f;
@@ -1415,6 +1420,7 @@ __global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, ui
         const Hit g = closest_hit<true>(S, P, o, sray, alive, 1, deferred SRT_PROF_ARG);
         if (alive) {
             c += g.prim >= first_mesh_prim ? 4u : 1u;
+            cb += g.prim >= first_mesh_prim ? 384u : 64u;
             if (g.prim < 0) {
                 alive = false;
             } else {
@@ -1424,8 +1430,11 @@ __global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, ui
             }
         }
     }
-    for (int off = 8; off > 0; off >>= 1) c += __shfl_down(c, off, 16);
-    if (k == 0 && block < n_blocks) cost[block] = c;
+    for (int off = 8; off > 0; off >>= 1) c += __shfl_down(c, off, 16), cb += __shfl_down(cb, off, 16);
+    if (k == 0 && block < n_blocks) {
+        cost[block] = c;
+        if (balance_cost) balance_cost[block] = cb;
+    }
 }
 
 // The probe estimate is 16 one-sample paths per block: noisy.  Costs vary smoothly over the image except at object

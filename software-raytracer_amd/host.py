@@ -23,7 +23,7 @@ EXPORTS = [
     "srt_host_renderer_accumulation_frames", "srt_host_renderer_wait", "srt_host_renderer_read_framebuffer",
     "srt_host_renderer_read_accumulator", "srt_host_renderer_stats", "srt_host_renderer_handle",
     "srt_host_multi_create", "srt_host_multi_destroy", "srt_host_multi_set_scene", "srt_host_multi_configure",
-    "srt_host_multi_render_samples", "srt_host_multi_read_framebuffer", "srt_host_multi_band", "srt_host_multi_stats",
+    "srt_host_multi_render_samples", "srt_host_multi_read_framebuffer", "srt_host_multi_band", "srt_host_multi_stats", "srt_host_multi_balance",
 ]
 
 _lib = None
@@ -104,6 +104,7 @@ def load_library():
     L.srt_host_multi_read_framebuffer.argtypes = [vp, vp, C.c_size_t]
     L.srt_host_multi_band.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.srt_host_multi_stats.argtypes = [vp, C.POINTER(Stats), C.c_int]
+    L.srt_host_multi_balance.argtypes = [vp]
     L.srt_host_renderer_handle.restype = vp
     _lib = L
     return L
@@ -331,6 +332,10 @@ class MultiRenderer:
         out = np.empty((self.height, self.width), dtype=np.uint32)
         self._ck(self.L.srt_host_multi_read_framebuffer(self._h, out.ctypes.data_as(C.c_void_p), self.width * 4))
         return out
+
+    def balance_bands(self):
+        """Bands of equal estimated cost (srt_estimate_row_costs) instead of equal height."""
+        self._ck(self.L.srt_host_multi_balance(self._h))
 
     def band(self, i):
         b, e = C.c_int(), C.c_int()

@@ -147,6 +147,10 @@ std::vector<float> PathTraceRenderer::ReadAccumulator() {
 // ---- MultiGpuRenderer -------------------------------------------------------------------
 MultiGpuRenderer::MultiGpuRenderer(const std::vector<int>& devices, int width, int height) : width_(width), height_(height) {
     if (devices.empty() || (int)devices.size() > height) throw RendererError(SRT_ERR_INVALID_ARG, "MultiGpuRenderer: need 1 <= devices <= height");
+    {
+        const int n = (int)devices.size(), q = height / n, r = height % n;
+        for (int k = 0; k <= n; ++k) bounds_.push_back(k * q + (k < r ? k : r));
+    }
     try {
         for (int d : devices) parts_.push_back(new PathTraceRenderer(d, width, height));
         for (size_t i = 0; i < parts_.size(); ++i) {
@@ -165,9 +169,36 @@ MultiGpuRenderer::~MultiGpuRenderer() {
 }
 
 void MultiGpuRenderer::Band(size_t i, int* begin, int* end) const {
-    const int n = (int)parts_.size(), q = height_ / n, r = height_ % n, k = (int)i;
-    *begin = k * q + (k < r ? k : r);
-    *end = *begin + q + (k < r ? 1 : 0);
+    *begin = bounds_[i];
+    *end = bounds_[i + 1];
+}
+
+void MultiGpuRenderer::BalanceBands() {
+    const int n = (int)parts_.size();
+    if (n < 2) return;
+    std::vector<float> cost((size_t)height_);
+    PathTraceRenderer& p0 = *parts_[0];
+    p0.Wait();
+    p0.PushCamera();
+    int rc = srt_estimate_row_costs(p0.handle(), p0.MAXBOUNCES < 0 ? 0 : p0.MAXBOUNCES, p0.seed, cost.data());
+    if (rc != SRT_OK) {
+        const char* msg = srt_last_error(p0.handle());
+        throw RendererError(rc, std::string("srt_estimate_row_costs: ") + (msg ? msg : "?"));
+    }
+    std::vector<double> prefix((size_t)height_ + 1, 0.0);
+    for (int i = 0; i < height_; ++i) prefix[(size_t)i + 1] = prefix[(size_t)i] + (cost[(size_t)i] > 0 ? cost[(size_t)i] : 0.0);
+    const double total = prefix[(size_t)height_];
+    bounds_[0] = 0;
+    for (int k = 1; k < n; ++k) {  // first row whose prefix cost reaches k/n of the total, rounded to 8 rows, every band >= 1 row
+        const int lo = bounds_[(size_t)k - 1] + 1, hi = height_ - (n - k);
+        int i = lo;
+        while (i < hi && prefix[(size_t)i] < total * k / n) ++i;
+        const int j = ((i + 4) / 8) * 8;
+        if (j >= lo && j <= hi) i = j;
+        bounds_[(size_t)k] = i < lo ? lo : (i > hi ? hi : i);
+    }
+    bounds_[(size_t)n] = height_;
+    for (int k = 0; k < n; ++k) parts_[(size_t)k]->SetRowBand(bounds_[(size_t)k], bounds_[(size_t)k + 1]);
 }
 
 void MultiGpuRenderer::SetScene(const Scene& scene) {

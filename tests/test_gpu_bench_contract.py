@@ -34,14 +34,21 @@ def test_single_gpu_line():
     assert cb["parity_bit_exact"] is True  # the GPU frame and the oracle's frame of the same sample are identical
 
 
-def test_two_rank_rehearsal():
+@pytest.mark.parametrize("balance,port", [("equal", 29571), ("probe", 29573)])
+def test_two_rank_rehearsal(balance, port):
+    """Two ranks sharing the GPU over gloo: equal bands + one dist.gather (the default), and bands of equal estimated
+    cost from srt_estimate_row_costs (no collective, every rank computes the same split) + one padded dist.gather."""
     env = dict(os.environ, SRT_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--width", "640", "--height", "360", "--spp", "8"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--width", "640", "--height", "360", "--spp", "8", "--balance", balance], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["stripe_parity_vs_single_device"] is True
     bands = d["config"]["bands"]
     assert bands[0][0] == 0 and bands[-1][1] == 360 and bands[0][1] == bands[1][0]
     assert len(d["per_rank"]) == 2
+    if balance == "equal":
+        assert bands[0][1] == 180 and "calibration_launches" not in d["config"]
+    else:
+        assert bands[0][1] > 180 and d["config"]["calibration_launches"] == 1  # Scene1: sky on top, the upper band is taller

@@ -47,6 +47,33 @@ def test_multi_renderer_equals_single_device_and_oracle(srt, oracle, name, n_par
     pt.close()
 
 
+def test_balanced_bands_equal_the_single_device_frame(srt):
+    """MultiGpuRenderer::BalanceBands: bands of equal ESTIMATED cost (srt_estimate_row_costs) — the frame must not change,
+    the bands must, and the estimate must be the same every time (all ranks of a multi-process job rely on that)."""
+    w, h, n_parts = 640, 360, 4
+    scene = srt.host.Scene(scene_path("Scene1"))
+    objs, n = scene.objects_copy()
+    pt = srt.PathTracer(w, h)
+    pt.set_scene(objs, n)
+    pt.set_camera(srt.default_camera())
+    c1, c2 = pt.estimate_row_costs(8, 0), pt.estimate_row_costs(8, 0)
+    assert c1 == c2 and len(c1) == h and min(c1) > 0
+    assert sum(c1[h // 2:]) > 3 * sum(c1[:h // 2])  # Scene1: the bottom half (floor, grid) costs far more than the sky
+    pt.render(spp=4, bounces=8, seed=0)
+    m = srt.host.MultiRenderer([0] * n_parts, w, h)
+    m.set_scene(scene)
+    m.configure(fov=55, max_bounces=8, seed=0)
+    equal = [m.band(i) for i in range(n_parts)]
+    m.balance_bands()
+    bands = [m.band(i) for i in range(n_parts)]
+    assert bands != equal and bands[0][0] == 0 and bands[-1][1] == h and all(bands[i][1] == bands[i + 1][0] for i in range(n_parts - 1))
+    assert bands[0][1] - bands[0][0] > bands[-1][1] - bands[-1][0]  # the sky band is the tallest
+    m.render_samples(4)
+    assert np.array_equal(m.framebuffer(), pt.framebuffer())
+    m.close()
+    pt.close()
+
+
 def test_gather_band_argument_checks(srt):
     a, b, c = srt.PathTracer(64, 32), srt.PathTracer(64, 32), srt.PathTracer(32, 32)
     with pytest.raises(srt.SrtError):
