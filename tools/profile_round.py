@@ -72,6 +72,28 @@ def main():
         st = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)
         if st:
             open(os.path.join(out, "kernel_stats_%s.csv" % name), "w").write(open(st[0]).read())
+        # the same trace, FULL-SIZE dispatches only (largest grid per kernel): bench.py's 8-row priming launch and
+        # its 1-bounce probe would otherwise dilute the averages of kernel_stats.csv
+        tr = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)
+        if tr:
+            import csv
+
+            per = {}
+            for row in csv.DictReader(open(tr[0])):
+                if "srt::" not in row["Kernel_Name"]:
+                    continue
+                grid = 1
+                for ax in "XYZ":
+                    grid *= int(row.get("Grid_Size_" + ax, 1) or 1)
+                kn = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                per.setdefault(kn, []).append((grid, (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6))
+            dur = {}
+            for kn, v in per.items():
+                g = max(x[0] for x in v)
+                ms = [x[1] for x in v if x[0] == g]
+                dur[kn] = {"grid_threads": g, "calls": len(ms), "mean_ms": sum(ms) / len(ms), "min_ms": min(ms), "max_ms": max(ms),
+                           "first_ms": ms[0], "dropped_smaller_dispatches": len(v) - len(ms)}
+            json.dump(dur, open(os.path.join(out, "kernel_durations_%s.json" % name), "w"), indent=1, sort_keys=True)
         # 3. counters, one group per pass
         r = run([sys.executable, os.path.join(ROOT, "tools", "pmc_collect.py"), "profile_%s/pmc_%s" % (rnd, name), "--groups", "hbm_r,hbm_w,sq1,sq2", "--"] + args +
                 ["--steps", "3", "--warmup", "2"], cwd=ROOT, timeout=1500)
