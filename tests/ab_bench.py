@@ -19,9 +19,13 @@ ap.add_argument("--bounces", type=int, default=8)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--mesh", type=int, default=0)
+ap.add_argument("--lib", default="", help="a development library built elsewhere (A/B of two source versions on one box)")
 a = ap.parse_args()
 srt = importlib.import_module("software-raytracer_amd")
-srt.capi.use_dev_library()
+if a.lib:
+    srt.capi._LIB = a.lib
+else:
+    srt.capi.use_dev_library()
 L = srt.load_library()
 L.srt_debug_set_variant.argtypes = [C.c_void_p, C.c_int]
 path = os.path.join(ROOT, "software-raytracer_amd", "scenes", a.scene + ".json")
