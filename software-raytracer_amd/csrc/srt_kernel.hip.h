@@ -521,8 +521,16 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                 S.res[lane] = ((unsigned long long)okey(best) << 32) | 0xFFFFFFFFull;  // no triangle yet
                 int batch = 64;
                 bool strict = false;
-#if defined(SRT_STATS) && SRT_STATS == 4  // make dev STATS=4: where a mesh phase spends its wave-cycles (tests/mesh_stats.py)
+#if defined(SRT_STATS) && SRT_STATS == 6  // make dev STATS=6: wave-cycles per part of a round, attributed where the waits fall (no forced waits)
+                long long st6[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SRT_T6(var) const long long var = (long long)__builtin_readcyclecounter()
+#else
+#define SRT_T6(var)
+#endif
+#if defined(SRT_STATS) && (SRT_STATS == 4 || SRT_STATS == 5)  // make dev STATS=4: where a mesh phase spends its wave-cycles (tests/mesh_stats.py); 5 = phase totals only (no waits inside the rounds)
                 const long long st_t0 = (long long)__builtin_readcyclecounter();
+#endif
+#if defined(SRT_STATS) && SRT_STATS == 4
                 long long st_node = 0, st_leaf = 0, st_wait = 0;
                 int st_nr = 0, st_lr = 0;
 #endif
@@ -552,6 +560,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                         // Nodes first, until 64 leaves wait: a node's 8 children are spread over 8 / 4 / 2 / 1 lanes so that the
                         // wave stays full however few items wait; a leaf gets four lanes, one triangle each — one memory
                         // round trip per leaf round instead of one per triangle.
+                        SRT_T6(t6a);
                         const bool node_round = nN > 0 && nL < 64;
                         const int takeL = node_round ? 0 : (nL < 16 ? nL : 16);
                         const int lanesN = 64 - 4 * takeL;
@@ -602,6 +611,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                         const V3 ro = v3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
                         const V3 rd = v3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
                         const float rpad = __shfl(pad, src);
+                        SRT_T6(t6b);
 #if defined(SRT_STATS) && SRT_STATS == 4
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                         st_wait += (long long)__builtin_readcyclecounter() - st_r0;
@@ -677,6 +687,11 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                                 mask = m4 << first;
                             }
                             if (!onN) mask = 0u;
+#if defined(SRT_STATS) && SRT_STATS == 6
+                            asm volatile("" ::"v"(mask));
+                            SRT_T6(t6c);
+                            st6[0] += t6b - t6a, st6[1] += t6c - t6b, st6[3] += 1;
+#endif
                             const unsigned tag = (unsigned)src << 26;
                             {  // surviving inner children -> node LIFO
                                 unsigned m = mask & innermask;
@@ -721,6 +736,11 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                                     nL += tot;
                                 }
                             }
+#if defined(SRT_STATS) && SRT_STATS == 6
+                            __builtin_amdgcn_wave_barrier();
+                            SRT_T6(t6d);
+                            st6[2] += t6d - t6c;
+#endif
                         }
                         else {
                             const float4 a = r0, b = r1, c = r2;
@@ -741,6 +761,11 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                             // the merge key is (ordered t || global triangle id): the id order is (list order of the object,
                             // triangle index), i.e. the tie rule; atomicMin makes the merge order-independent
                             if (ok) atomicMin(&S.res[src], ((unsigned long long)okey(t) << 32) | (unsigned)__float_as_int(b.w));
+#if defined(SRT_STATS) && SRT_STATS == 6
+                            __builtin_amdgcn_wave_barrier();
+                            SRT_T6(t6e);
+                            st6[4] += t6b - t6a, st6[5] += t6e - t6b, st6[6] += 1;
+#endif
                         }
                         __builtin_amdgcn_wave_barrier();
 #if defined(SRT_STATS) && SRT_STATS == 4
@@ -764,6 +789,15 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                     if (SRT_STATS == 1 && overflow) SRT_STAT(6, 1);
 #endif
                 }
+#if defined(SRT_STATS) && SRT_STATS == 6
+                for (int i = 0; i < 7; ++i) SRT_STAT(i, st6[i]);
+                SRT_STAT(7, 1);
+#endif
+#if defined(SRT_STATS) && SRT_STATS == 5
+                SRT_STAT(0, (long long)__builtin_readcyclecounter() - st_t0);
+                SRT_STAT(4, st_rounds);
+                SRT_STAT(6, 1);
+#endif
 #if defined(SRT_STATS) && SRT_STATS == 4
                 SRT_STAT(0, (long long)__builtin_readcyclecounter() - st_t0);
                 SRT_STAT(1, st_node);
@@ -938,7 +972,11 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     const int tile_h = P.tile_h;
     // which block of tiles: the hardware starts workgroups in linear order, wg_order maps that order to
     // blocks sorted by decreasing cost so that the expensive ones do not end up in the tail
+#if defined(SRT_STATS) && SRT_STATS == 5
+    const long long t_start = (long long)__builtin_readcyclecounter();
+#else
     const long long t_start = P.wg_cost ? (long long)__builtin_readcyclecounter() : 0;
+#endif
     uint32_t block_id = blockIdx.y * gridDim.x + blockIdx.x;
     if (P.wg_order) block_id = P.wg_order[block_id];
     const int bx = (int)(block_id % gridDim.x), by = (int)(block_id / gridDim.x);
@@ -1281,6 +1319,9 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
 #if defined(SRT_STATS) && SRT_STATS == 3
     SRT_TICK(7);
     for (int i = 0; i < 8; ++i) SRT_STAT(i, prof.acc[i] > 0 ? prof.acc[i] : 0);
+#endif
+#if defined(SRT_STATS) && SRT_STATS == 5
+    SRT_STAT(7, (long long)__builtin_readcyclecounter() - t_start);  // the wave's whole life
 #endif
     if ((P.flags & 2u) || P.wg_cost) {  // SRT_RENDER_COUNT_RAYS / cost feedback for the dispatch order
         unsigned long long tot = rays;

@@ -38,6 +38,17 @@ if mode == 4:
     print("phases %d: %.0f wave-cycles each | rounds %.1f per phase, %.0f cycles each (%.0f until the item's rows and ray are there) | outside rounds %.0f cycles per phase  [the probes inflate all of it]" %
           (o[6], o[0] / ph, o[4] / ph, o[1] / nr, o[3] / nr, (o[0] - o[1]) / ph))
     sys.exit(0)
+if mode == 6:
+    nr, lr = max(o[3], 1), max(o[6], 1)
+    print("phases %d | node rounds %.1f per phase: pop + issue loads and shuffles %.0f, slab tests (the wait for the rows falls here) %.0f, pushes %.0f cycles | "
+          "leaf rounds %.1f per phase: pop + issue %.0f, triangle test + merge %.0f cycles" %
+          (o[7], o[3] / max(o[7], 1), o[0] / nr, o[1] / nr, o[2] / nr, o[6] / max(o[7], 1), o[4] / lr, o[5] / lr))
+    sys.exit(0)
+if mode == 5:
+    ph = max(o[6], 1)
+    print("phases %d, %.1f rounds each, %.0f wave-cycles per phase = %.0f per round | in mesh phases: %.1f %% of all wave-cycles (%.3g of %.3g), kernel %.3f ms" %
+          (o[6], o[4] / ph, o[0] / ph, o[0] / max(o[4], 1), 100.0 * o[0] / max(o[7], 1), o[0], o[7], st.kernel_ms))
+    sys.exit(0)
 if mode == 2:
     print("histogram by rays entering the phase (1-2, 3-8, 9-32, 33-64): phases", o[:4], "rounds", o[4:])
     sys.exit(0)

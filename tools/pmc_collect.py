@@ -27,6 +27,11 @@ GROUPS = {
     "sq1": ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE"],
     "sq2": ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"],
     "sq3": ["SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VMEM_WR", "SQ_WAIT_INST_LDS"],
+    # the vector memory path (mesh kernels: gathers of BVH nodes and triangles)
+    "tcp1": ["TCP_TOTAL_CACHE_ACCESSES", "TCP_TCC_READ_REQ", "TCP_TCC_READ_REQ_LATENCY", "TCP_PENDING_STALL_CYCLES"],
+    "tcp2": ["TCP_TCP_LATENCY", "TCP_TOTAL_READ", "TCP_UTCL1_TRANSLATION_MISS", "TCP_UTCL1_TRANSLATION_HIT"],
+    "tcc": ["TCC_HIT", "TCC_MISS", "TCC_REQ", "TCC_EA0_RDREQ"],
+    "ta": ["TA_TA_BUSY", "TA_ADDR_STALLED_BY_TC_CYCLES", "TA_DATA_STALLED_BY_TC_CYCLES", "TA_TOTAL_WAVEFRONTS"],
 }
 
 
