@@ -131,6 +131,17 @@ struct Prof {
 constexpr int MESH_WAVE_BYTES = (MESH_QN + MESH_QL) * 4;
 constexpr int WG_MESH_SCRATCH_BYTES = MESH_WAVE_BYTES * WG_TILES_X * WG_TILES_Y;
 
+// inclusive prefix sum over the 64 lanes of a wave (all lanes active): four shifts inside the rows of 16, then the row totals
+// are passed on with the row-broadcast controls — six v_add_u32_dpp
+__device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
 __device__ __forceinline__ float clamp0(float v) { return v < 0 ? 0.0f : v; }  // Common.hpp:254-257
 
 // (float)rand() / RAND_MAX (Raytracer.cpp:93-95,165,182) for r in [0, 32767]: the correctly rounded
@@ -424,6 +435,9 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             if (bp >= 0) bord = S.order(bp);
             const float pad = 1e-5f * (((fabsf(o.x - P.mesh_center[0]) + fabsf(o.y - P.mesh_center[1])) + fabsf(o.z - P.mesh_center[2])) + P.mesh_r1) + 1e-7f;
             const V3 inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+            // slopes clamped to 2^96 for the traversal: an axis the ray (almost) does not move along keeps its
+            // sign-correct, still astronomically large plane distances without inf * 0
+            const V3 rinv_own = v3(fminf(fmaxf(inv.x, -0x1p96f), 0x1p96f), fminf(fmaxf(inv.y, -0x1p96f), 0x1p96f), fminf(fmaxf(inv.z, -0x1p96f), 0x1p96f));
             // root box (kernel argument, no memory access): most rays never come near the mesh, and
             // when no lane of the wave does, the whole phase is skipped
             bool go;
@@ -505,34 +519,11 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                         n += cnt;
                     }
                 };
-                // exclusive wave prefix sum of per-lane counts <= 8 (bit-sliced through ballots; empty slices are skipped)
-                auto prefix_small = [&](int cnt, int& prefix, int& total) {
-                    prefix = 0;
-                    total = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(((cnt >> b) & 1) != 0);
-                        if (bal != 0ull) {
-                            prefix += mbcnt64(bal) << b;
-                            total += __builtin_popcountll(bal) << b;
-                        }
-                    }
-                };
                 S.res[lane] = ((unsigned long long)okey(best) << 32) | 0xFFFFFFFFull;  // no triangle yet
                 int batch = 64;
                 bool strict = false;
-#if defined(SRT_STATS) && SRT_STATS == 6  // make dev STATS=6: wave-cycles per part of a round, attributed where the waits fall (no forced waits)
-                long long st6[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define SRT_T6(var) const long long var = (long long)__builtin_readcyclecounter()
-#else
-#define SRT_T6(var)
-#endif
-#if defined(SRT_STATS) && (SRT_STATS == 4 || SRT_STATS == 5)  // make dev STATS=4: where a mesh phase spends its wave-cycles (tests/mesh_stats.py); 5 = phase totals only (no waits inside the rounds)
+#if defined(SRT_STATS) && SRT_STATS == 5  // make dev STATS=5: wave-cycles per mesh phase and per wave life (tests/mesh_stats.py)
                 const long long st_t0 = (long long)__builtin_readcyclecounter();
-#endif
-#if defined(SRT_STATS) && SRT_STATS == 4
-                long long st_node = 0, st_leaf = 0, st_wait = 0;
-                int st_nr = 0, st_lr = 0;
 #endif
 #ifdef SRT_STATS
                 const int st_cls = n_go <= 2 ? 0 : n_go <= 8 ? 1 : n_go <= 32 ? 2 : 3;
@@ -560,15 +551,13 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                         // Nodes first, until 64 leaves wait: a node's 8 children are spread over 8 / 4 / 2 / 1 lanes so that the
                         // wave stays full however few items wait; a leaf gets four lanes, one triangle each — one memory
                         // round trip per leaf round instead of one per triangle.
-                        SRT_T6(t6a);
                         const bool node_round = nN > 0 && nL < 64;
-                        const int takeL = node_round ? 0 : (nL < 16 ? nL : 16);
-                        const int lanesN = 64 - 4 * takeL;
-                        int logP = 0, takeN = 0;
+#ifdef SRT_STATS
+                        st_rounds += 1;
+#endif
                         if (node_round) {
-                            if (strict) {
-                                logP = 3, takeN = 1;
-                            } else {
+                            int logP = 3, takeN = 1;
+                            if (!strict) {
                                 logP = nN <= 8 ? 3 : nN <= 16 ? 2 : nN <= 32 ? 1 : 0;
                                 takeN = nN < (64 >> logP) ? nN : (64 >> logP);
                                 // leave room for the expected pushes (about 3 per item)
@@ -578,55 +567,30 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                                 room = room < 8 ? 8 : room;
                                 takeN = takeN < room ? takeN : room;
                             }
-                        }
-                        nN -= takeN;  // the items [nN, nN + takeN) and [nL, nL + takeL) are popped
-                        nL -= takeL;
+                            nN -= takeN;  // the items [nN, nN + takeN) are popped
 #ifdef SRT_STATS
-                        if (SRT_STATS == 1) {
-                            SRT_STAT(2, takeN > 0 ? 1 : 0);
-                            SRT_STAT(3, takeN);
-                            SRT_STAT(4, takeL > 0 ? 1 : 0);
-                            SRT_STAT(5, takeL);
-                        }
-                        st_rounds += 1;
+                            if (SRT_STATS == 1) {
+                                SRT_STAT(2, 1);
+                                SRT_STAT(3, takeN);
+                            }
 #endif
-#if defined(SRT_STATS) && SRT_STATS == 4
-                        const long long st_r0 = (long long)__builtin_readcyclecounter();
-#endif
-                        const int slotN = lane >> logP, sub = lane & ((1 << logP) - 1);
-                        const int ll = lane - lanesN, subL = ll & 3;
-                        const bool onL = ll >= 0, onN = !onL && slotN < takeN;
-                        const unsigned item = onN ? qn[nN + slotN] : onL ? ql[nL + (ll >> 2)] : 0u;
-                        const int src = (int)(item >> 26), code = (int)(item & 0x3FFFFFFu);
-                        // the rows of the item — five of a node or three of a triangle, in the same registers — are requested
-                        // before the ray is fetched, so that the memory round trip overlaps the shuffles
-                        const int lcnt = (code & 3) + 1;  // leaf items: (first triangle) * 4 + (count - 1)
-                        // (every lane loads — idle lanes the root / the first triangle: a load under a lane mask would make the
-                        // compiler wait for it right here, to merge the registers with those of the lanes that do not load)
-                        // (the top levels of the tree need no copy in LDS: they stay in the vector L1, a copy measured no faster)
-                        const float4* rowp = node_round ? P.bvh_nodes + 5 * (size_t)code : P.bvh_tris + 3 * (size_t)((code >> 2) + (subL < lcnt ? subL : 0));
-                        const float4 r0 = rowp[0], r1 = rowp[1], r2 = rowp[2];
-                        float4 r3 = make_float4(0, 0, 0, 0), r4 = r3;
-                        if (node_round) r3 = rowp[3], r4 = rowp[4];
-                        const V3 ro = v3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
-                        const V3 rd = v3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
-                        const float rpad = __shfl(pad, src);
-                        SRT_T6(t6b);
-#if defined(SRT_STATS) && SRT_STATS == 4
-                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                        st_wait += (long long)__builtin_readcyclecounter() - st_r0;
-#endif
-                        if (node_round) {
-                            const float4 h0 = r0, h1 = r1, q0 = r2, q1 = r3, q2 = r4;
+                            const int slotN = lane >> logP, sub = lane & ((1 << logP) - 1);
+                            const bool onN = slotN < takeN;
+                            const unsigned item = onN ? qn[nN + slotN] : 0u;
+                            const int src = (int)(item >> 26), code = (int)(item & 0x3FFFFFFu);
+                            // the five rows of the node are requested before the ray is fetched, so that the memory round trip overlaps
+                            // the shuffles.  (Every lane loads — idle lanes the root: a load under a lane mask would make the compiler wait
+                            // for it right here, to merge the registers with those of the lanes that do not load.  The top levels of the
+                            // tree need no copy in LDS: they stay in the vector L1, a copy measured no faster.)
+                            const float4* rowp = P.bvh_nodes + 5 * (size_t)code;
+                            const float4 h0 = rowp[0], h1 = rowp[1], q0 = rowp[2], q1 = rowp[3], q2 = rowp[4];
+                            const V3 ro = v3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
+                            const V3 rinv = v3(__shfl(rinv_own.x, src), __shfl(rinv_own.y, src), __shfl(rinv_own.z, src));
+                            const float rpad = __shfl(pad, src);
                             const float thr = unkey((unsigned)(S.res[src] >> 32));
                             // a child is entered only if a triangle inside could still beat the ray's best hit: entry distance
                             // <= (thr + 1e-5) / 0.9999 (written as an upper bound of it), and <= 10001
                             const float thr2 = fminf(__builtin_fmaf(fabsf(thr), 2e-4f, thr + 1e-5f), 10001.0f);
-                            // slopes clamped to 2^96: an axis the ray (almost) does not move along keeps its
-                            // sign-correct, still astronomically large plane distances without inf * 0
-                            const float BIG = 0x1p96f;
-                            const V3 rinv = v3(fminf(fmaxf(__builtin_amdgcn_rcpf(rd.x), -BIG), BIG), fminf(fmaxf(__builtin_amdgcn_rcpf(rd.y), -BIG), BIG),
-                                               fminf(fmaxf(__builtin_amdgcn_rcpf(rd.z), -BIG), BIG));
                             const unsigned ex = __float_as_uint(h0.w);
                             const unsigned innermask = ex >> 24, lw = __float_as_uint(h1.z), leafmask = lw & 255u, counts = lw >> 8;
                             // plane distance = q * (cell * rinv) + ((origin -/+ pad) - ro) * rinv, one FMA per plane
@@ -687,93 +651,101 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                                 mask = m4 << first;
                             }
                             if (!onN) mask = 0u;
-#if defined(SRT_STATS) && SRT_STATS == 6
-                            asm volatile("" ::"v"(mask));
-                            SRT_T6(t6c);
-                            st6[0] += t6b - t6a, st6[1] += t6c - t6b, st6[3] += 1;
-#endif
                             const unsigned tag = (unsigned)src << 26;
-                            {  // surviving inner children -> node LIFO
-                                unsigned m = mask & innermask;
-                                int pre, tot;
-                                prefix_small(__builtin_popcount(m), pre, tot);
-                                if (nN + tot > MESH_QN) {
-                                    overflow = true;
-                                } else {
+                            // exclusive prefix sums of both survivor counts in ONE wave scan (inner count in the low half, leaf count in
+                            // the high half; six DPP adds instead of eight ballot rounds)
+                            unsigned mi = mask & innermask, ml = mask & leafmask;
+                            const unsigned both = (unsigned)__builtin_popcount(mi) | ((unsigned)__builtin_popcount(ml) << 16);
+                            const unsigned incl = wave_inclusive_scan(both);
+                            const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63), excl = incl - both;
+                            const int totN = (int)(total & 0xFFFFu), totL = (int)(total >> 16);
+                            if (nN + totN > MESH_QN || nL + totL > MESH_QL) {
+                                overflow = true;
+                            } else {
+                                if (totN > 0) {  // surviving inner children -> node LIFO
                                     const unsigned first_inner = __float_as_uint(h1.x);
-                                    int w = nN + pre;
-                                    while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
-                                        if (m != 0u) {
-                                            const unsigned below = (m & (0u - m)) - 1u;  // mask of the children before the lowest survivor
+                                    int w = nN + (int)(excl & 0xFFFFu);
+                                    while (__builtin_amdgcn_ballot_w64(mi != 0u) != 0ull) {
+                                        if (mi != 0u) {
+                                            const unsigned below = (mi & (0u - mi)) - 1u;  // mask of the children before the lowest survivor
                                             qn[w++] = tag | (first_inner + (unsigned)__builtin_popcount(innermask & below));
-                                            m &= m - 1u;
+                                            mi &= mi - 1u;
                                         }
                                     }
-                                    nN += tot;
+                                    nN += totN;
                                 }
-                            }
-                            {  // surviving leaf children -> leaf queue, item = (first triangle) * 4 + (count - 1)
-                                unsigned m = mask & leafmask;
-                                int pre, tot;
-                                prefix_small(__builtin_popcount(m), pre, tot);
-                                if (nL + tot > MESH_QL) {
-                                    overflow = true;
-                                } else if (tot > 0) {
+                                if (totL > 0) {  // surviving leaf children -> leaf queue, item = (first triangle) * 4 + (count - 1)
                                     const unsigned first_tri = __float_as_uint(h1.y);
-                                    int w = nL + pre;  // (over this round's popped items: their reads have long completed)
-                                    while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
-                                        if (m != 0u) {
-                                            const unsigned bit = m & (0u - m), below = bit - 1u;
+                                    int w = nL + (int)(excl >> 16);  // (over this round's popped items: their reads have long completed)
+                                    while (__builtin_amdgcn_ballot_w64(ml != 0u) != 0ull) {
+                                        if (ml != 0u) {
+                                            const unsigned bit = ml & (0u - ml), below = bit - 1u;
                                             const unsigned below2 = bit * bit - 1u;  // the count fields (2 bits each) of the children before
                                             const unsigned cf = counts & below2;
                                             const unsigned first = first_tri + (unsigned)__builtin_popcount(leafmask & below) + (unsigned)__builtin_popcount(cf & 0x5555u) +
                                                                    2u * (unsigned)__builtin_popcount(cf & 0xAAAAu);
                                             const unsigned c2 = 2u * (unsigned)__builtin_ctz(bit);
                                             ql[w++] = tag | (first * 4u + ((counts >> c2) & 3u));
-                                            m &= m - 1u;
+                                            ml &= ml - 1u;
                                         }
                                     }
-                                    nL += tot;
+                                    nL += totL;
                                 }
                             }
-#if defined(SRT_STATS) && SRT_STATS == 6
-                            __builtin_amdgcn_wave_barrier();
-                            SRT_T6(t6d);
-                            st6[2] += t6d - t6c;
-#endif
                         }
                         else {
-                            const float4 a = r0, b = r1, c = r2;
-                            // Moller-Trumbore, binary32, no FMA, fixed order (the oracle's triangle_raytrace)
-                            V3 pv = v3(rd.y * c.z - rd.z * c.y, rd.z * c.x - rd.x * c.z, rd.x * c.y - rd.y * c.x);
-                            float det = (b.x * pv.x + b.y * pv.y) + b.z * pv.z;
-                            float idet = 1.0f / det;
-                            V3 tv = v3(ro.x - a.x, ro.y - a.y, ro.z - a.z);
-                            float u = ((tv.x * pv.x + tv.y * pv.y) + tv.z * pv.z) * idet;
-                            V3 qv = v3(tv.y * b.z - tv.z * b.y, tv.z * b.x - tv.x * b.z, tv.x * b.y - tv.y * b.x);
-                            float vv = ((rd.x * qv.x + rd.y * qv.y) + rd.z * qv.z) * idet;
-                            float t = ((c.x * qv.x + c.y * qv.y) + c.z * qv.z) * idet;
-                            bool ok = onL & (subL < lcnt) & (fabsf(det) >= 1e-12f) & (u >= 0.0f) & (u <= 1.0f) & (vv >= 0.0f) & (u + vv <= 1.0f) &
-                                      (t >= (float)0.01) & (t <= 10000.0f);
+                            // a leaf round spreads a leaf's <= 4 triangles over 4 / 2 / 1 lanes by the number of leaves waiting: up to 16
+                            // leaves take one trip, up to 32 two, up to 64 four — one round instead of up to four
+                            const int logL = nL <= 16 ? 2 : nL <= 32 ? 1 : 0;
+                            const int takeL = nL < (64 >> logL) ? nL : (64 >> logL);
+                            const int trips = 4 >> logL;
+                            nL -= takeL;  // the items [nL, nL + takeL) are popped
+#ifdef SRT_STATS
+                            if (SRT_STATS == 1) {
+                                SRT_STAT(4, 1);
+                                SRT_STAT(5, takeL);
+                            }
+#endif
+                            const int slotL = lane >> logL, subL = lane & ((1 << logL) - 1);
+                            const bool onL = slotL < takeL;
+                            const unsigned item = onL ? ql[nL + slotL] : 0u;
+                            const int src = (int)(item >> 26), code = (int)(item & 0x3FFFFFFu);
+                            const int lcnt = (code & 3) + 1;  // leaf items: (first triangle) * 4 + (count - 1)
+                            const float4* rowp = P.bvh_tris + 3 * (size_t)((code >> 2) + (subL < lcnt ? subL : 0));  // (idle lanes: triangle 0)
+                            float4 a = rowp[0], b = rowp[1], c = rowp[2];
+                            const V3 ro = v3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
+                            const V3 rd = v3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
+                            for (int j = 0;; ++j) {
+                                const int k = subL + (j << logL);  // this trip's triangle of the leaf
+                                const bool more = j + 1 < trips;   // (wave-uniform)
+                                float4 na = a, nb = b, nc = c;
+                                if (more) {  // the next trip's rows are requested before this trip's arithmetic
+                                    const int kn = subL + ((j + 1) << logL);
+                                    const float4* np = P.bvh_tris + 3 * (size_t)((code >> 2) + (kn < lcnt ? kn : 0));
+                                    na = np[0], nb = np[1], nc = np[2];
+                                }
+                                // Moller-Trumbore, binary32, no FMA, fixed order (the oracle's triangle_raytrace)
+                                V3 pv = v3(rd.y * c.z - rd.z * c.y, rd.z * c.x - rd.x * c.z, rd.x * c.y - rd.y * c.x);
+                                float det = (b.x * pv.x + b.y * pv.y) + b.z * pv.z;
+                                float idet = 1.0f / det;
+                                V3 tv = v3(ro.x - a.x, ro.y - a.y, ro.z - a.z);
+                                float u = ((tv.x * pv.x + tv.y * pv.y) + tv.z * pv.z) * idet;
+                                V3 qv = v3(tv.y * b.z - tv.z * b.y, tv.z * b.x - tv.x * b.z, tv.x * b.y - tv.y * b.x);
+                                float vv = ((rd.x * qv.x + rd.y * qv.y) + rd.z * qv.z) * idet;
+                                float t = ((c.x * qv.x + c.y * qv.y) + c.z * qv.z) * idet;
+                                bool ok = onL & (k < lcnt) & (fabsf(det) >= 1e-12f) & (u >= 0.0f) & (u <= 1.0f) & (vv >= 0.0f) & (u + vv <= 1.0f) &
+                                          (t >= (float)0.01) & (t <= 10000.0f);
 #ifdef SRT_DEV
-                            if (P.flags & 0x200u) ok = false;
+                                if (P.flags & 0x200u) ok = false;
 #endif
-                            // the merge key is (ordered t || global triangle id): the id order is (list order of the object,
-                            // triangle index), i.e. the tie rule; atomicMin makes the merge order-independent
-                            if (ok) atomicMin(&S.res[src], ((unsigned long long)okey(t) << 32) | (unsigned)__float_as_int(b.w));
-#if defined(SRT_STATS) && SRT_STATS == 6
-                            __builtin_amdgcn_wave_barrier();
-                            SRT_T6(t6e);
-                            st6[4] += t6b - t6a, st6[5] += t6e - t6b, st6[6] += 1;
-#endif
+                                // the merge key is (ordered t || global triangle id): the id order is (list order of the object,
+                                // triangle index), i.e. the tie rule; atomicMin makes the merge order-independent
+                                if (ok) atomicMin(&S.res[src], ((unsigned long long)okey(t) << 32) | (unsigned)__float_as_int(b.w));
+                                if (!more) break;
+                                a = na, b = nb, c = nc;
+                            }
                         }
                         __builtin_amdgcn_wave_barrier();
-#if defined(SRT_STATS) && SRT_STATS == 4
-                        {
-                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                            st_node += (long long)__builtin_readcyclecounter() - st_r0, st_nr += 1;
-                        }
-#endif
                     }
                     if (!overflow) {
                         pend &= ~selmask;
@@ -789,22 +761,9 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                     if (SRT_STATS == 1 && overflow) SRT_STAT(6, 1);
 #endif
                 }
-#if defined(SRT_STATS) && SRT_STATS == 6
-                for (int i = 0; i < 7; ++i) SRT_STAT(i, st6[i]);
-                SRT_STAT(7, 1);
-#endif
 #if defined(SRT_STATS) && SRT_STATS == 5
                 SRT_STAT(0, (long long)__builtin_readcyclecounter() - st_t0);
                 SRT_STAT(4, st_rounds);
-                SRT_STAT(6, 1);
-#endif
-#if defined(SRT_STATS) && SRT_STATS == 4
-                SRT_STAT(0, (long long)__builtin_readcyclecounter() - st_t0);
-                SRT_STAT(1, st_node);
-                SRT_STAT(2, st_leaf);
-                SRT_STAT(3, st_wait);
-                SRT_STAT(4, st_nr);
-                SRT_STAT(5, st_lr);
                 SRT_STAT(6, 1);
 #endif
 #ifdef SRT_STATS
