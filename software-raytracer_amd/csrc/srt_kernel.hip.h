@@ -332,15 +332,11 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             }
             if (!active) mask = 0ull;
             const int K4 = S.K >> 2;
-            // exclusive prefix sum of popcount(mask) over the wave, bit-sliced through ballots
+            // exclusive prefix sum of popcount(mask) over the wave: one DPP scan (six adds; seven ballot slices before)
             const int cnt = __builtin_popcountll(mask);
-            int prefix = 0, total = 0;
-            for (int b = 0; b < 7; ++b) {
-                unsigned long long bal = __builtin_amdgcn_ballot_w64(((cnt >> b) & 1) != 0);
-                prefix += (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u)) << b;
-                total += __builtin_popcountll(bal) << b;
-            }
-            total = __builtin_amdgcn_readfirstlane(total);
+            const unsigned incl = wave_inclusive_scan((unsigned)cnt);
+            const int prefix = (int)incl - cnt;
+            const int total = __builtin_amdgcn_readlane((int)incl, 63);
             SRT_TICK(4);
             if (total > 0 && total <= WORK_MAX) {
                 const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -429,6 +425,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
     // Moller-Trumbore test (~1e-6 * |o - v0|) and of the plane distances below (~4e-7 of the same
     // magnitudes); the slab comparison itself has slack for the approximate reciprocals.
     int btri = -1;               // winner's position in the triangle array (-1: not a triangle)
+    V3 tri_n = v3(0, 0, 0);      // its e1 x e2
     int bord = 0x7fffffff;       // list index of the best analytic hit's object
     if constexpr (MESH) {
         if (P.n_tris > 0) {
@@ -778,11 +775,14 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                     if (go && gid != 0xFFFFFFFFu) {
                         const float tm = unkey((unsigned)(r >> 32));
                         const int pos = P.bvh_gidpos[gid];
-                        const int ordm = __float_as_int(P.bvh_tris[3 * pos + 2].w);
-                        const bool win = (tm < best) | ((tm == best) & (ordm < bord));
+                        // the triangle's primitive id, edges (for the normal) and list index in ONE round trip
+                        const float pw = P.bvh_tris[3 * pos].w;
+                        const float4 e1 = P.bvh_tris[3 * pos + 1], e2 = P.bvh_tris[3 * pos + 2];
+                        const bool win = (tm < best) | ((tm == best) & (__float_as_int(e2.w) < bord));
                         best = win ? tm : best;
-                        bp = win ? __float_as_int(P.bvh_tris[3 * pos].w) : bp;
+                        bp = win ? __float_as_int(pw) : bp;
                         btri = win ? pos : btri;
+                        if (win) tri_n = v3(e1.y * e2.z - e1.z * e2.y, e1.z * e2.x - e1.x * e2.z, e1.x * e2.y - e1.y * e2.x);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -793,8 +793,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
     h.prim = bp;
     h.p = v3(o.x + d.x * best, o.y + d.y * best, o.z + d.z * best);  // Object.hpp:136 / :229
     if (MESH && btri >= 0) {
-        const float4 b = P.bvh_tris[3 * btri + 1], c = P.bvh_tris[3 * btri + 2];
-        V3 n = normalized(v3(b.y * c.z - b.z * c.y, b.z * c.x - b.x * c.z, b.x * c.y - b.y * c.x));  // unit geometric normal
+        V3 n = normalized(tri_n);  // unit geometric normal, e1 x e2
         if (dot3(n, d) > 0) n = v3(n.x * -1, n.y * -1, n.z * -1);                                      // turned against the ray
         h.n = n;
     } else if (bp >= nsT) {
