@@ -1099,11 +1099,18 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         // fold point (ring capacity); slots do not wait for each other.
         uint32_t own_next = own_done;
         int rot = 0;  // wave-uniform rotation of the slot priority
+        const int fold_pace = (63 + n_hit) / n_hit;
 
         while (true) {
             SRT_TICK(7);
-            // ---- fold finished samples, in order, into the owners' running means
-            for (int it = 0; it < depth; ++it) {
+            // ---- fold finished samples, in order, into the owners' running means.  A slot finishes at most as many samples per
+            // step as lanes work for it (64 / n_hit on average): that many iterations keep pace, and the few lanes that have a
+            // second sample ready (finished out of order) wait for the next step, where they share the iteration with many
+            // others — a further iteration for their sake costs the whole wave a fold.  Once the hand-out has ended, or nothing
+            // runs, everything ready is folded.
+            const bool drain = __builtin_amdgcn_ballot_w64(busy) == 0ull || __builtin_amdgcn_ballot_w64(own_next < count) == 0ull;
+            const int fold_its = drain || fold_pace > depth ? depth : fold_pace;
+            for (int it = 0; it < fold_its; ++it) {
                 bool ready = false;
                 float4 e = make_float4(0, 0, 0, 0);
                 if (own_done < count) {
