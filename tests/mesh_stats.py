@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development aid: traversal counters of the mesh kernel (builds libsrt_pathtrace_dev_stats<N>.so: STATS=1 counters,
-SRT_STATS_MODE=2 histogram by rays per phase, SRT_STATS_MODE=4 wave-cycles inside a phase).
+SRT_STATS_MODE=2 histogram by rays per phase, SRT_STATS_MODE=5 wave-cycles per phase and per wave life).
 usage: python tests/mesh_stats.py [--mesh 224] [--spp 8] [--bounces 8] [--width 1920 --height 1080 --rows a,b] [--json]"""
 import argparse, ctypes as C, importlib, json, os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,17 +33,6 @@ for _ in range(2):  # the second launch uses the learned dispatch order; counter
     st = pt.stats()
     L.srt_debug_read_stats(out)
 o = list(out)
-if mode == 4:
-    ph, nr = max(o[6], 1), max(o[4], 1)
-    print("phases %d: %.0f wave-cycles each | rounds %.1f per phase, %.0f cycles each (%.0f until the item's rows and ray are there) | outside rounds %.0f cycles per phase  [the probes inflate all of it]" %
-          (o[6], o[0] / ph, o[4] / ph, o[1] / nr, o[3] / nr, (o[0] - o[1]) / ph))
-    sys.exit(0)
-if mode == 6:
-    nr, lr = max(o[3], 1), max(o[6], 1)
-    print("phases %d | node rounds %.1f per phase: pop + issue loads and shuffles %.0f, slab tests (the wait for the rows falls here) %.0f, pushes %.0f cycles | "
-          "leaf rounds %.1f per phase: pop + issue %.0f, triangle test + merge %.0f cycles" %
-          (o[7], o[3] / max(o[7], 1), o[0] / nr, o[1] / nr, o[2] / nr, o[6] / max(o[7], 1), o[4] / lr, o[5] / lr))
-    sys.exit(0)
 if mode == 5:
     ph = max(o[6], 1)
     print("phases %d, %.1f rounds each, %.0f wave-cycles per phase = %.0f per round | in mesh phases: %.1f %% of all wave-cycles (%.3g of %.3g), kernel %.3f ms" %
