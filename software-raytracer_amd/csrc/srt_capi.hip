@@ -552,11 +552,27 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     // tiles give too few workgroups to fill 256 CUs x 4 resident workgroups and leave nothing to balance
     // the tail with; halve the tile (twice the workgroups, same lanes at work in each wave's path pool)
     // until there are about four rounds of workgroups.  Results do not depend on the tiling.
+    // Progressive blocks (steps > 1): when every pixel of a block ends up with a value that one lane can produce — the
+    // launch starts the frame (all pixels of a block then hold the same running mean) or adds ONE sample (each pixel folds
+    // the block's colour into its own mean) — the launch's lanes are blocks, not pixels: 1 / steps^2 of the lanes, one
+    // ray per block, steps^2 pixel stores per lane (Raytracer.cpp:235-248).  Anything else (several samples onto an
+    // accumulated frame) keeps one lane per pixel with the block's ray traced once per wave tile.
+    const bool bgrid = K.steps > 1 && ((K.flags & SRT_RENDER_RESET) || p->sample_count == 1);
+    long long grid_w = W, grid_h = K.rows;
+    if (bgrid) {
+        const long long sw = K.stripe_width > 0 ? K.stripe_width : W;
+        grid_w = ((W + sw - 1) / sw) * ((sw + K.steps - 1) / K.steps);
+        grid_h = (K.y0 + K.rows - 1) / K.steps - K.y0 / K.steps + 1;  // block rows that meet the band (scene rows)
+        K.flags |= srt::KF_BLOCK_GRID;
+    }
+    K.bgrid_w = (int32_t)grid_w, K.bgrid_h = (int32_t)grid_h;
     const int tile_env = dev_switches().tile_h;
     int tile_h = srt::TILE_H;
-    const long long wg_x = (W + srt::WG_W - 1) / srt::WG_W;
+    const long long wg_x = (grid_w + srt::WG_W - 1) / srt::WG_W;
     const long long want = 15LL * ctx->cu_count;  // ~4 rounds of the 4 workgroups a CU holds; measured on bands of 30..400 rows
-    while (tile_h > 1 && p->sample_count >= 16 && wg_x * ((K.rows + tile_h * srt::WG_TILES_Y - 1) / (tile_h * srt::WG_TILES_Y)) < want) tile_h >>= 1;
+    while (tile_h > 1 && p->sample_count >= 16 && wg_x * ((grid_h + tile_h * srt::WG_TILES_Y - 1) / (tile_h * srt::WG_TILES_Y)) < want) tile_h >>= 1;
+    // a block grid is 1 / steps^2 of the pixel grid: keep at least two workgroups per CU (the waves' run time is latency)
+    while (bgrid && tile_h > 1 && wg_x * ((grid_h + tile_h * srt::WG_TILES_Y - 1) / (tile_h * srt::WG_TILES_Y)) < 2LL * ctx->cu_count) tile_h >>= 1;
     if (tile_env == 8 || tile_env == 4 || tile_env == 2 || tile_env == 1) tile_h = tile_env;
     // Sample-chunked launch, for 64 samples per pixel and more: keep the full 8x8 tiles but give every tile
     // to several workgroups, each tracing one chunk (>= 16) of the samples and storing the colours; a
@@ -609,7 +625,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     K.chunk = defer ? chunk : 0;
     K.sample_rows = ctx->d_samples;
     K.tile_masks = ctx->d_tile_masks;
-    dim3 grid((unsigned)wg_x, (unsigned)((K.rows + tile_h * srt::WG_TILES_Y - 1) / (tile_h * srt::WG_TILES_Y)), (unsigned)chunks);
+    dim3 grid((unsigned)wg_x, (unsigned)((grid_h + tile_h * srt::WG_TILES_Y - 1) / (tile_h * srt::WG_TILES_Y)), (unsigned)chunks);
     dim3 block(srt::WG_THREADS);
     // Cost-ordered dispatch.  The hardware starts workgroups in linear order; with the natural order the
     // last ones to start are whatever lies at the top of the band, and the chip idles while a few expensive
@@ -620,7 +636,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     const bool order_env = dev_switches().lpt;
     bool record = false;
     const size_t nwg = (size_t)grid.x * grid.y;
-    if (order_env && !ctx->order_disabled && nwg >= 2048 && p->sample_count >= 4 && !(p->flags & SRT_RENDER_PREVIEW)) {
+    if (order_env && !ctx->order_disabled && nwg >= 2048 && p->sample_count >= 4 && !(p->flags & SRT_RENDER_PREVIEW) && !bgrid) {
         if (nwg > ctx->wg_capacity) {
             SRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->d_wg_cost) (void)hipFree(ctx->d_wg_cost);
@@ -648,7 +664,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             }
         }
     }
-    if (order_env && !ctx->order_disabled && ctx->wg_capacity >= nwg && nwg >= 2048 && p->sample_count >= 4 && !(p->flags & SRT_RENDER_PREVIEW)) {
+    if (order_env && !ctx->order_disabled && ctx->wg_capacity >= nwg && nwg >= 2048 && p->sample_count >= 4 && !(p->flags & SRT_RENDER_PREVIEW) && !bgrid) {
         const hipError_t arrived = ctx->recording ? hipEventQuery(ctx->ev_cost) : hipErrorNotReady;
         if (arrived != hipSuccess) (void)hipGetLastError();  // "not ready" must not surface as this launch's error
         if (arrived == hipSuccess) {  // costs have arrived: make the order
@@ -714,7 +730,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     // instantiation: mesh or not, scene image in LDS or HBM, full tiles / small tiles (multi-sample
     // hand-out) / sample chunks; variants 1 / 3 are a development aid for in-process A/B timing.
     // All are bit-identical.
-    const bool in_lds = ctx->scene_in_lds[img], multi = tile_h < srt::TILE_H || (K.steps > 1 && !(K.flags & SRT_RENDER_PREVIEW));
+    const bool in_lds = ctx->scene_in_lds[img], multi = tile_h < srt::TILE_H || (K.steps > 1 && !(K.flags & SRT_RENDER_PREVIEW)) || bgrid;
     auto launch = [&](auto k_lds, auto k_lds_multi, auto k_lds_defer, auto k_hbm, auto k_hbm_multi, auto k_hbm_defer) {
         if (in_lds && defer) hipLaunchKernelGGL(k_lds_defer, grid, block, lds_bytes, ctx->stream, K);
         else if (in_lds && multi) hipLaunchKernelGGL(k_lds_multi, grid, block, lds_bytes, ctx->stream, K);

@@ -65,6 +65,7 @@ struct KernelParams {
     int32_t max_bounces;
     uint32_t seed, flags;
     int32_t steps, stripe_width, selected;  // progressive blocks (:233-248), selectedObject (:53)
+    int32_t bgrid_w, bgrid_h;               // flags & KF_BLOCK_GRID: the launch's lanes are BLOCKS, this many columns / rows of them
     // scene image layout (srt_scene_image.h)
     int32_t nu4, nc, K, nsT, nb;
     int32_t off_bounds, off_box, off_mat;
@@ -95,6 +96,9 @@ struct KernelParams {
     unsigned long long* ray_counter;
 };
 
+// internal KernelParams.flags bit (srt_render sets it): progressive-block launch whose lanes stand for steps x steps
+// blocks instead of pixels — a lane traces its block's ray and writes all of the block's pixels
+constexpr uint32_t KF_BLOCK_GRID = 0x10u;
 constexpr int TILE_W = 8, TILE_H = 8;       // per wavefront
 constexpr int WG_TILES_X = 2, WG_TILES_Y = 2;  // waves per workgroup
 constexpr int WG_THREADS = 64 * WG_TILES_X * WG_TILES_Y;
@@ -870,13 +874,16 @@ __device__ __forceinline__ void accumulate_sample(const KernelParams& P, float4&
     }
 }
 // SetScreenPixel tone-map + pack + the two stores (Raytracer.cpp:64,73-75)
-__device__ __forceinline__ void store_pixel(const KernelParams& P, uint32_t pix, const float4 acc) {
-    P.accumulator[pix] = acc;
+__device__ __forceinline__ uint32_t tone_map(const float4 acc) {
     float r = clamp0(acc.x / clamp0(1.0f + acc.x));
     float g = clamp0(acc.y / clamp0(1.0f + acc.y));
     float b = clamp0(acc.z / clamp0(1.0f + acc.z));
     float a = clamp0(acc.w / clamp0(0.0f + acc.w));
-    uint32_t px = pack_channel(a) << 24 | pack_channel(r) << 16 | pack_channel(g) << 8 | pack_channel(b);
+    return pack_channel(a) << 24 | pack_channel(r) << 16 | pack_channel(g) << 8 | pack_channel(b);
+}
+__device__ __forceinline__ void store_pixel(const KernelParams& P, uint32_t pix, const float4 acc) {
+    P.accumulator[pix] = acc;
+    const uint32_t px = tone_map(acc);
     const uint32_t py = pix / (uint32_t)P.width, pxx = pix - py * (uint32_t)P.width;
     P.framebuffer[(size_t)(P.height - 1 - (int)py) * P.width + pxx] = px;
 }
@@ -941,26 +948,100 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     const int tx = bx * WG_W + (wave % WG_TILES_X) * TILE_W + (lane & (TILE_W - 1));
     const int ty = by * (tile_h * WG_TILES_Y) + (wave / WG_TILES_X) * tile_h + (lane / TILE_W);
     const int W = P.width, H = P.height;
-    const bool in_range = tx < W && ty < P.rows && (lane / TILE_W) < tile_h;
-    const int x = in_range ? tx : 0, y = in_range ? (P.y0 + ty) : P.y0;
-    const uint32_t pixel = (uint32_t)(x + y * W);
-
     // ---- progressive blocks (Raytracer.cpp:235-248): the ray of a steps x steps block goes
     // through the block's anchor pixel; blocks start at the worker stripe's first column.
-    int ax = x, ay = y;
-    if (P.steps > 1) {
-        const int s0 = P.stripe_width > 0 ? (x / P.stripe_width) * P.stripe_width : 0;
-        ax = s0 + ((x - s0) / P.steps) * P.steps;
-        ay = (y / P.steps) * P.steps;
+    // Block grid (MULTI instantiation, KF_BLOCK_GRID): the launch's lanes are blocks — column tx of the grid is block
+    // tx % n of stripe tx / n (n = blocks per stripe), row ty the ty-th block row that meets the band — so the launch does
+    // work in proportion to the number of blocks, like renderArea: one RaytraceScene per block, steps^2 SetScreenPixels.
+    const bool bgrid = MULTI && (P.flags & KF_BLOCK_GRID) != 0;
+    bool in_range_;
+    int x_, y_, ax, ay;
+    if (bgrid) {
+        const int sw = P.stripe_width > 0 ? P.stripe_width : W;
+        const int per_stripe = (sw + P.steps - 1) / P.steps;
+        const int stripe = tx / per_stripe;
+        ax = stripe * sw + (tx - stripe * per_stripe) * P.steps;
+        ay = (P.y0 / P.steps + ty) * P.steps;
+        in_range_ = tx < P.bgrid_w && ty < P.bgrid_h && ax < W && ay < P.y0 + P.rows && (lane / TILE_W) < tile_h;
+        if (!in_range_) ax = 0, ay = (P.y0 / P.steps) * P.steps;
+        x_ = ax, y_ = ay;
+    } else {
+        in_range_ = tx < W && ty < P.rows && (lane / TILE_W) < tile_h;
+        x_ = in_range_ ? tx : 0, y_ = in_range_ ? (P.y0 + ty) : P.y0;
+        ax = x_, ay = y_;
+        if (P.steps > 1) {
+            const int s0 = P.stripe_width > 0 ? (x_ / P.stripe_width) * P.stripe_width : 0;
+            ax = s0 + ((x_ - s0) / P.steps) * P.steps;
+            ay = (y_ / P.steps) * P.steps;
+        }
     }
+    const bool in_range = in_range_;
+    const int x = x_, y = y_;
+    const uint32_t pixel = (uint32_t)(x + y * W);  // (block grid: the anchor; it may lie above the band)
     const uint32_t rng_pixel = (uint32_t)(ax + ay * W);
+    // Block grid: the pixels of the wave's finished blocks are written by ALL lanes together — lane groups of steps^2 lanes
+    // take a block each (steps = 8: a block per pass, eight rows of eight neighbouring pixels) — instead of every block's
+    // lane looping over its own steps^2 pixels.  `val` is the block's running mean (the launch starts the frame: the same
+    // for all its pixels, tone-mapped once) or its ONE sample colour (`keep`: every pixel folds it into its own mean).
+    // A block's pixels: inside its stripe, the image and the band.
+    auto write_blocks = [&](bool have, int bx0, int by0, float4 val, bool keep) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(have);
+        if (m == 0ull) return;
+        const int n = __builtin_popcountll(m);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        float4* sv = S.ring;                                      // [64] values
+        unsigned* sa = reinterpret_cast<unsigned*>(S.work);       // [64] anchor x | [64] anchor y | [64] tone-mapped pixel
+        __builtin_amdgcn_wave_barrier();
+        if (have) {
+            sv[rank] = val;
+            sa[rank] = (unsigned)bx0, sa[64 + rank] = (unsigned)by0;
+            sa[128 + rank] = keep ? 0u : tone_map(val);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int steps = P.steps, per = steps * steps;
+        const int L = per < 64 ? per : 64, G = 64 / L;  // lanes per block, blocks per pass
+        const int g = lane / L, ql = lane - g * L;
+        for (int b0 = 0; b0 < n; b0 += G) {
+            const int b = b0 + g;
+            const bool on = g < G && b < n;
+            const int bi = on ? b : 0;
+            const int x0 = (int)sa[bi], y0b = (int)sa[64 + bi];
+            const float4 v = sv[bi];
+            const uint32_t px = sa[128 + bi];
+            int x_end = x0 + steps;
+            if (P.stripe_width > 0) {
+                const int s_end = (x0 / P.stripe_width + 1) * P.stripe_width;
+                x_end = x_end < s_end ? x_end : s_end;
+            }
+            x_end = x_end < W ? x_end : W;
+            int y_hi = y0b + steps;
+            y_hi = y_hi < P.y0 + P.rows ? y_hi : P.y0 + P.rows;
+            for (int q = ql; q < per; q += 64) {  // (one trip for steps <= 8)
+                const int j = q / steps, i = q - j * steps;
+                const int xx = x0 + i, yy = y0b + j;
+                if (on && xx < x_end && yy >= P.y0 && yy < y_hi) {
+                    const uint32_t pp = (uint32_t)(xx + yy * W);
+                    if (keep) {
+                        float4 a = P.accumulator[pp];
+                        accumulate_sample(P, a, RGB{v.x, v.y, v.z}, 0);
+                        P.accumulator[pp] = a;
+                        P.framebuffer[(size_t)(H - 1 - yy) * W + xx] = tone_map(a);
+                    } else {
+                        P.accumulator[pp] = v;
+                        P.framebuffer[(size_t)(H - 1 - yy) * W + xx] = px;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
     // Blocks are traced ONCE per wave tile, by the first lane of the tile that lies in the block (its leader), and
     // every pixel of the block folds the leader's sample colours into its own running mean (renderArea :239-248 does
     // exactly that: one RaytraceScene per block, one SetScreenPixel per pixel).  A block that straddles tiles is traced
     // once in each.  Launches with steps > 1 use the MULTI instantiation (few slots per tile, several samples each).
     int lead_lane = lane;
     if constexpr (MULTI) {
-        if (P.steps > 1 && !(P.flags & 4u)) {  // (the preview shader traces nothing: every pixel shades for itself)
+        if (P.steps > 1 && !(P.flags & 4u) && !bgrid) {  // (the preview shader traces nothing: every pixel shades for itself)
             const uint32_t key = in_range ? rng_pixel : 0xFFFFFFFFu - (uint32_t)lane;  // lanes without a pixel lead themselves
             unsigned long long same = 0ull;
             for (int i = 0; i < 64; ++i)
@@ -998,6 +1079,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     const bool preview = (P.flags & 4u) != 0;
     const bool pix_traced = in_range && h0.prim >= 0 && B > 0 && !preview;  // (the same for every pixel of a block)
     const bool traced = pix_traced && is_leader;
+    float4 untraced_val = make_float4(0, 0, 0, 0);
     if (in_range && !pix_traced && (!DEFER || blockIdx.z == 0)) {  // (chunked: once, by the first chunk, for all samples)
         RGB c;
         if (h0.prim < 0) {
@@ -1031,10 +1113,21 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             float4 m1 = S.mat(h0.prim, 1);
             c = RGB{clamp0(m1.y), clamp0(m1.z), clamp0(m1.w)};
         }
-        float4 acc = reset ? make_float4(0, 0, 0, 0) : P.accumulator[pixel];
-        for (uint32_t i = 0; i < P.sample_count; ++i) accumulate(acc, c, i);
+        if (bgrid) {  // (written below, by the whole wave)
+            untraced_val = make_float4(c.r, c.g, c.b, 0.0f);
+            if (reset) {
+                untraced_val = make_float4(0, 0, 0, 0);
+                for (uint32_t i = 0; i < P.sample_count; ++i) accumulate(untraced_val, c, i);
+            }
+        } else {
+            float4 acc = reset ? make_float4(0, 0, 0, 0) : P.accumulator[pixel];
+            for (uint32_t i = 0; i < P.sample_count; ++i) accumulate(acc, c, i);
+            write_pixel(pixel, acc);
+        }
         if (is_leader) rays += P.sample_count;  // one GetClosestObject call per block and frame
-        write_pixel(pixel, acc);
+    }
+    if constexpr (MULTI) {
+        if (bgrid) write_blocks(in_range && !pix_traced, ax, ay, untraced_val, !reset);
     }
 
     // ---- wave-level path pool -----------------------------------------------------------------
@@ -1074,7 +1167,11 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         float4 acc = make_float4(0, 0, 0, 0);
         // progressive blocks: a slot is a block, and every PIXEL lane of the block folds the slot's colours into the
         // running mean of its own pixel, in step with the slot's owner (same ring entries, same test, same iteration)
-        const bool blocks = MULTI && P.steps > 1 && !(P.flags & 4u);
+        const bool blocks = MULTI && P.steps > 1 && !(P.flags & 4u) && !bgrid;
+        // block grid: the owner folds ONE running mean for the whole block when the launch starts the frame (all pixels then
+        // hold the same value); when it continues a frame the launch has one sample (srt_render), the owner keeps its
+        // colour and every pixel of the block folds it into its own accumulator at the end
+        const bool bgrid_keep = bgrid && !reset;
         const bool fold_px = blocks && pix_traced;
         const int fslot = __builtin_popcountll(hitmask & ((1ull << lead_lane) - 1ull));  // the leader's slot
         uint32_t fdone = fold_px ? 0u : count;
@@ -1082,7 +1179,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             if (fold_px && !reset) acc = P.accumulator[pixel];
         } else if (owner) {
             own_pixel = __float_as_uint(rec[lane * 12 + 11]);
-            if (!DEFER && !reset) acc = P.accumulator[own_pixel];
+            if (!DEFER && !reset && !bgrid) acc = P.accumulator[own_pixel];
         }
 
         // path state of the task this lane is running
@@ -1138,6 +1235,8 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 if (ready) {
                     if constexpr (DEFER)  // row (tile, sample) of the sample buffer: 64 slots of 16 B, coalesced
                         P.sample_rows[(tile_id * P.sample_count + s_base + own_done) * 64 + lane] = e;
+                    else if (MULTI && bgrid_keep)
+                        acc = e;
                     else
                         accumulate(acc, RGB{e.x, e.y, e.z}, own_done);
                     ++own_done;
@@ -1276,6 +1375,9 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         }
         if (blocks) {
             if (fold_px) write_pixel(pixel, acc);
+        } else if (MULTI && bgrid) {
+            const int oy = (int)(own_pixel / (uint32_t)W), ox = (int)(own_pixel - (uint32_t)oy * (uint32_t)W);
+            write_blocks(owner, ox, oy, acc, bgrid_keep);
         } else if (!DEFER && owner) {
             write_pixel(own_pixel, acc);
         }

@@ -292,6 +292,55 @@ def test_progressive_blocks_with_sample_chunks(srt, oracle):
     pt.close()
 
 
+@pytest.mark.parametrize("name", ["Scene3", "Scene_indirect"])
+def test_block_grid_launches(srt, oracle, name):
+    """Progressive blocks (Raytracer.cpp:233-248) through the launches whose lanes are BLOCKS (srt_render picks them when the
+    launch starts the frame or adds one sample): odd frame sizes, stripes that the block size does not divide, blocks of more
+    than 64 pixels, row bands that cut blocks, one sample folded onto an accumulated frame — and the one-lane-per-pixel
+    fallback (several samples onto an accumulated frame).  Bits against the oracle; one ray per block and bounce."""
+    w, h = 157, 91
+    pt, objs, n = _pt(srt, name, w, h)
+    for steps in (2, 3, 5, 8, 11):
+        for sw in (0, w // 16 + 1):
+            kw = dict(bounces=4, seed=17, steps=steps, stripe_width=sw)
+            # the launch starts the frame: one and several samples
+            for spp in (1, 3):
+                pt.render(spp=spp, count_rays=True, **kw)
+                ofb, oacc, orays = _oracle_frame(oracle, objs, n, w, h, spp=spp, **kw)
+                assert np.array_equal(pt.framebuffer(), ofb), (steps, sw, spp)
+                assert np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32)), (steps, sw, spp)
+                # (the oracle's default walk evaluates the block's ray for every pixel; renderArea's own loop nest — the
+                # literal mode, 16 column stripes, one sample — traces once per block, and so does the block grid)
+                if spp == 1 and sw > 0:
+                    lfb, _, lrays = _oracle_frame(oracle, objs, n, w, h, spp=1, split=oracle.SPLIT_REF_COLS, threads=16, **kw)
+                    assert np.array_equal(lfb, ofb) and pt.stats().rays == lrays, (steps, sw, pt.stats().rays, lrays, orays)
+            # a full-resolution frame of two samples, then ONE sample in blocks folded onto it (every pixel its own mean)
+            pt.render(spp=2, bounces=4, seed=17)
+            _, acc2, _ = _oracle_frame(oracle, objs, n, w, h, spp=2, bounces=4, seed=17)
+            pt.render(spp=1, first_sample=3, reset=False, **kw)
+            ofb, oacc, _ = _oracle_frame(oracle, objs, n, w, h, spp=1, first_sample=3, reset=False, accumulator=acc2, **kw)
+            assert np.array_equal(pt.framebuffer(), ofb), (steps, sw, "keep")
+            assert np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32)), (steps, sw, "keep")
+            # several samples onto that frame: one lane per pixel
+            pt.render(spp=3, first_sample=4, reset=False, **kw)
+            ofb, oacc2, _ = _oracle_frame(oracle, objs, n, w, h, spp=3, first_sample=4, reset=False, accumulator=oacc, **kw)
+            assert np.array_equal(pt.framebuffer(), ofb), (steps, sw, "fallback")
+            assert np.array_equal(pt.accumulator().view(np.uint32), oacc2.view(np.uint32)), (steps, sw, "fallback")
+    # row bands that cut through blocks, rendered one after the other, give the single-launch frame
+    kw = dict(spp=1, bounces=4, seed=5, steps=5, stripe_width=w // 16 + 1)
+    pt.render(**kw)
+    full_fb, full_acc = pt.framebuffer(), pt.accumulator()
+    pt2 = srt.PathTracer(w, h)
+    pt2.set_scene(objs, n)
+    pt2.set_camera(srt.default_camera())
+    for rb, re in [(0, 1), (1, 16), (16, 17), (17, 64), (64, 91)]:
+        pt2.render(rows=(rb, re), **kw)
+    assert np.array_equal(pt2.framebuffer(), full_fb)
+    assert np.array_equal(pt2.accumulator().view(np.uint32), full_acc.view(np.uint32))
+    pt2.close()
+    pt.close()
+
+
 def test_sample_chunks_extremes(srt, oracle):
     """Sample-chunked launches at the edges: thousands of samples on a frame smaller than one workgroup
     (hundreds of chunks per tile), and a band without a single traced pixel (all sky: every tile mask 0)."""
