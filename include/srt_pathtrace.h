@@ -149,7 +149,7 @@ typedef struct srt_render_params {
 } srt_render_params;
 
 typedef struct srt_stats {
-    uint64_t rays;          /* GetClosestObject calls (primary counted once per sample) */
+    uint64_t rays;          /* GetClosestObject calls (primary counted once per sample; steps > 1: per block, as renderArea traces) */
     uint64_t path_samples;  /* W_band * H_band * sample_count of the last render */
     float kernel_ms;        /* HIP-event time of the last render's kernel(s) on its stream */
     uint32_t sample_chunks; /* 1: one kernel traced and folded every sample; n > 1: the samples of a tile were split
