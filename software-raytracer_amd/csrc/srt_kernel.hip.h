@@ -473,10 +473,10 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             }
             // ---- wave-cooperative traversal of the 8-wide BVH.  Rays that come near the mesh put
             // (ray lane, node) items on a LIFO in LDS.  A node round pops items and tests the 8 quantized
-            // child boxes of each: with <= 8 items waiting, eight lanes share an item (one child per lane, so
-            // a lone ray still uses the wave and descends a level per round); with more, one lane per item
-            // loops over the children.  Surviving children are pushed with ballot prefix sums, leaves to a
-            // second queue that is drained a triangle per lane (<= 16 leaves waiting) or a leaf per lane.
+            // child boxes of each, spread over 8 / 4 / 2 / 1 lanes by the number of items waiting (a lone ray
+            // still uses the wave and descends a level per round).  Surviving children are pushed behind the
+            // offsets of one wave scan, leaves to a second queue that a leaf round drains — a leaf's <= 4
+            // triangles over 4 / 2 / 1 lanes.
             // A ray's best triangle is merged through a 64-bit LDS atomicMin on (ordered t || global
             // triangle id) — the id order is (list order of the object, triangle index), i.e. the tie
             // rule — and doubles as the culling distance.  The merge is idempotent, so when a queue would
@@ -484,7 +484,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             // popping one item per round (strict depth-first) is bounded by 7 * depth + 8 entries, which
             // the host checks against MESH_QN.
             //
-            // Deferral (path pool only): a mesh phase costs a chain of dependent memory round trips however
+            // Deferral (path pool only): a mesh phase costs the wave some seven rounds of ~350 instructions however
             // few rays take part, and most phases would be started by two or three stray bounce rays.  So
             // unless at least `defer_min` rays want the mesh — or no lane has anything else to do — the
             // rays are reported back as deferred: the pool parks them and offers them again next round.
@@ -549,9 +549,8 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                         // every round — rounds per phase 11.0 -> 9.9, but every round then runs both code paths, +8 % time; a
                         // leaf queue of single triangles, one per lane — fewer leaf rounds, but more queue traffic and the
                         // node rounds get throttled by the leaf queue's room, +7 %.)
-                        // Nodes first, until 64 leaves wait: a node's 8 children are spread over 8 / 4 / 2 / 1 lanes so that the
-                        // wave stays full however few items wait; a leaf gets four lanes, one triangle each — one memory
-                        // round trip per leaf round instead of one per triangle.
+                        // Nodes first, until 64 leaves wait.  The two kinds of round are separate branches — each pops, loads and
+                        // fetches its rays on its own — so that neither pays for selects between node and triangle data.
                         const bool node_round = nN > 0 && nL < 64;
 #ifdef SRT_STATS
                         st_rounds += 1;
