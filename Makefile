@@ -13,8 +13,8 @@ test-gpu: build
 bench: build
 	$(PY) bench.py
 
-profile:          # on an MI355X: regenerates profiles/r01 and profiles/traffic.json
-	bash tools/profile_round.sh r01
+profile:          # on an MI355X: regenerates profiles/r02, profiles/counters.json and profiles/mesh_counts.json
+	$(PY) tools/profile_round.py r02
 
 clean:
 	$(MAKE) -C software-raytracer_amd/csrc clean
