@@ -91,6 +91,44 @@ def test_random_scene_parity(srt, oracle, seed):
     pt.close()
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SRT_FUZZ_BLOCKS_N", "12"))))
+def test_random_scene_progressive_blocks(srt, oracle, seed):
+    """The same random scenes through progressive-block launches (steps 2..9, random stripe widths, row bands that cut
+    blocks, preview shader or path tracing, starting or continuing a frame, one or several samples): block-grid launches and
+    the one-lane-per-pixel fallback against the oracle's per-pixel walk."""
+    rng = np.random.default_rng(5000 + seed)
+    kind = ["unit", "far", "tiny", "mixed", "offset"][seed % 5]
+    objs, meshes, off, scale = _random_scene(oracle, rng, kind)
+    oarr, n = oracle.make_objects(objs)
+    marr, mn, keep = oracle.make_meshes(meshes)
+    w, h = int(rng.integers(40, 200)), int(rng.integers(30, 120))
+    cam = oracle.Camera()
+    pos = off - np.array([0, 0, 6.0]) * scale + rng.uniform(-1, 1, 3) * scale
+    basis = srt.host.rotate_about_axis([1, 0, 0, 0, 1, 0, 0, 0, 1], float(rng.uniform(-0.5, 0.5)), (0, 1, 0))
+    cam.position = oracle.f3(pos)
+    cam.right, cam.up, cam.forward = oracle.f3(basis[0:3]), oracle.f3(basis[3:6]), oracle.f3(basis[6:9])
+    cam.fov_degrees = int(rng.integers(15, 104))
+    steps = int(rng.integers(2, 10))
+    rb = int(rng.integers(0, h - 1))
+    re = int(rng.integers(rb + 1, h + 1))
+    kw = dict(spp=int(rng.choice([1, 1, 2, 5])), bounces=int(rng.integers(0, 6)), seed=int(rng.integers(0, 2**31)), first_sample=int(rng.integers(1, 50)),
+              reset=bool(rng.integers(0, 2)), steps=steps, stripe_width=int(rng.choice([0, w // 16 + 1, int(rng.integers(1, w + 5))])),
+              preview=bool(rng.uniform() < 0.3), rows=(rb, re))
+    acc0 = rng.uniform(0, 2, (h, w, 4)).astype(np.float32)
+    acc0[..., 3] = 0
+    pt = srt.PathTracer(w, h)
+    pt.set_meshes(C.cast(marr, C.POINTER(srt.Mesh)), mn)
+    pt.set_scene(C.cast(oarr, C.POINTER(srt.Object)), n)
+    pt.set_camera(srt.Camera.from_buffer_copy(bytes(cam)))
+    pt.write_accumulator(acc0)
+    pt.render(**kw)
+    ofb, oacc, _ = oracle.render(oarr, n, oracle.default_environment(), cam, w, h, accumulator=acc0, meshes=(marr, mn) if mn else None, **kw)
+    gacc = pt.accumulator()
+    assert np.array_equal(gacc.view(np.uint32), oacc.view(np.uint32)), (kind, n, kw, int((gacc.view(np.uint32) != oacc.view(np.uint32)).any(-1).sum()))
+    assert np.array_equal(pt.framebuffer(rows=(rb, re)), ofb[rb:re]), (kind, n, kw)
+    pt.close()
+
+
 @pytest.mark.parametrize("with_mesh", [False, True])
 def test_scene_larger_than_lds(srt, oracle, with_mesh):
     """3400 spheres + 60 boxes: the scene image (~220 KB) cannot sit in LDS, so the kernel reads it
