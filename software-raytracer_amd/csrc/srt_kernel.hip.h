@@ -99,6 +99,7 @@ struct KernelParams {
 // internal KernelParams.flags bit (srt_render sets it): progressive-block launch whose lanes stand for steps x steps
 // blocks instead of pixels — a lane traces its block's ray and writes all of the block's pixels
 constexpr uint32_t KF_BLOCK_GRID = 0x10u;
+constexpr uint32_t SRT_MESH_ORDER_W = 6u;  // block_cost_kernel: ordering cost of a ray that ends on a mesh, in analytic rays (as the balance cost)
 constexpr int TILE_W = 8, TILE_H = 8;       // per wavefront
 constexpr int WG_TILES_X = 2, WG_TILES_Y = 2;  // waves per workgroup
 constexpr int WG_THREADS = 64 * WG_TILES_X * WG_TILES_Y;
@@ -1513,7 +1514,7 @@ __global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, ui
     if (alive) {
         spec = (S.mat(h.prim, 0).y >= rand_unit(srt_mix32(rng) >> 17)) ? 1.0f : 0.0f;
         rng += 0x9E3779B9U;
-        c += h.prim >= first_mesh_prim ? 3u : 0u;
+        c += h.prim >= first_mesh_prim ? (SRT_MESH_ORDER_W - 1u) : 0u;
     }
     for (int bounce = 0; bounce < P.max_bounces && __builtin_amdgcn_ballot_w64(alive) != 0ull; ++bounce) {
         V3 o = v3(0, 0, 0);
@@ -1531,7 +1532,7 @@ __global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, ui
         }
         const Hit g = closest_hit<true>(S, P, o, sray, alive, 1, deferred SRT_PROF_ARG);
         if (alive) {
-            c += g.prim >= first_mesh_prim ? 4u : 1u;
+            c += g.prim >= first_mesh_prim ? SRT_MESH_ORDER_W : 1u;
             cb += g.prim >= first_mesh_prim ? 384u : 64u;
             if (g.prim < 0) {
                 alive = false;
