@@ -495,6 +495,7 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
 #endif
     const srt::SceneLayout& SL = ctx->layout[img];
     K.nu4 = SL.nu4;
+    K.nu = SL.nu;
     K.nc = SL.nc;
     K.K = SL.K;
     K.nsT = SL.nsT;

@@ -68,6 +68,7 @@ struct KernelParams {
     int32_t bgrid_w, bgrid_h;               // flags & KF_BLOCK_GRID: the launch's lanes are BLOCKS, this many columns / rows of them
     // scene image layout (srt_scene_image.h)
     int32_t nu4, nc, K, nsT, nb;
+    int32_t nu;  // uniform spheres that are not padding
     int32_t off_bounds, off_box, off_mat;
     int32_t scene_vec4;  // number of float4 in the scene image
     const float4* scene;
@@ -174,7 +175,7 @@ __device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.
 
 struct Lds {
     const float4* v;  // LDS base
-    int nu4, nc, K, nsT, nb, off_bounds, off_box, off_mat;
+    int nu4, nu, nc, K, nsT, nb, off_bounds, off_box, off_mat;
     unsigned long long* res;  // this wave's 64 result slots
     unsigned short* work;     // this wave's work list
     float* pix;               // this wave's 64 pixel records (12 floats each)
@@ -313,9 +314,23 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
     };
     SRT_TICK(2);
     // ---- 1. uniform spheres: broadcast ds_read_b128, 4 per trip
-    for (int j = 0; j < S.nu4; j += 4) {
+    for (int j = 0; j + 4 <= S.nu; j += 4) {
         const float4 s0 = S.v[j], s1 = S.v[j + 1], s2 = S.v[j + 2], s3 = S.v[j + 3];
         test4(s0, s1, s2, s3, j, o, d, active, best, bp);
+    }
+    if (S.nu & 3) {  // the last, partial group without its padding (Scene1 has 3 uniform spheres, Scene3 / Scene_indirect 2)
+        const int j = S.nu & ~3, rem = S.nu & 3;
+        const float4 s0 = S.v[j], s1 = S.v[j + 1], s2 = S.v[j + 2];
+        const Cand k0 = part1(s0, o, d, active);
+        Cand k1 = k0, k2 = k0;
+        bool any = k0.c;
+        if (rem >= 2) k1 = part1(s1, o, d, active), any |= k1.c;
+        if (rem == 3) k2 = part1(s2, o, d, active), any |= k2.c;
+        if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+            part2(k0, j, best, bp);
+            if (rem >= 2) part2(k1, j + 1, best, bp);
+            if (rem == 3) part2(k2, j + 2, best, bp);
+        }
     }
     SRT_TICK(3);
     // ---- 2. clustered spheres
@@ -901,7 +916,7 @@ __device__ __forceinline__ Lds make_lds(const KernelParams& P, float4* lds, int 
         image = lds;
     else
         image = P.scene;
-    return Lds{image, P.nu4, P.nc, P.K, P.nsT, P.nb, P.off_bounds, P.off_box, P.off_mat,
+    return Lds{image, P.nu4, P.nu, P.nc, P.K, P.nsT, P.nb, P.off_bounds, P.off_box, P.off_mat,
                reinterpret_cast<unsigned long long*>(scratch), reinterpret_cast<unsigned short*>(scratch + 64 * 8),
                reinterpret_cast<float*>(scratch + 64 * 8 + WORK_MAX * 2),
                reinterpret_cast<float4*>(scratch + 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4),

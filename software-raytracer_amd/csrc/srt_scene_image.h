@@ -55,6 +55,7 @@ namespace srt {
 
 struct SceneLayout {
     int nu4 = 0;      // uniform sphere slots (multiple of 4)
+    int nu = 0;       // uniform spheres actually there (the rest of the slots are dummies)
     int nc = 0;       // clusters (<= 64)
     int K = 4;        // sphere slots per cluster (multiple of 4)
     int nsT = 0;      // nu4 + nc*K
@@ -117,7 +118,8 @@ inline SceneLayout build_scene_image(const srt_object* objects, size_t count, bo
     L.n_spheres = (int)spheres.size();
     L.nb = (int)boxes.size();
     L.nm = (int)meshobjs.size();
-    L.nu4 = ((int)uni.size() + 3) & ~3;
+    L.nu = (int)uni.size();
+    L.nu4 = (L.nu + 3) & ~3;
     // order the small spheres along a Morton curve of their centres, then cut into clusters
     if (!small.empty()) {
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
@@ -142,6 +144,47 @@ inline SceneLayout build_scene_image(const srt_object* objects, size_t count, bo
         while ((int)((small.size() + K - 1) / K) > 64) K += 4;
         L.K = K;
         L.nc = (int)((small.size() + K - 1) / K);
+        // The Morton cut is only a starting point: where the spheres do not fill a regular grid it makes clusters that
+        // straddle gaps (Scene3 / Scene_indirect: bounding radii 0.54 .. 2.77 for spheres of radius 0.2), and the number of
+        // (ray, cluster) pairs that reach the exact tests grows with the clusters' cross-sections.  Exchange members between
+        // clusters while that lowers the sum of the squared bounding radii (deterministic sweep order; sizes stay as they
+        // are; any grouping is equally valid for the culling proof).  Those two scenes: sum of R^2 16.9 -> 4.9.
+        if (K == 4 && L.nc >= 2) {
+            auto radius2 = [&](const int* m, int n) {
+                double c[3] = {0, 0, 0};
+                for (int k = 0; k < n; ++k)
+                    for (int a = 0; a < 3; ++a) c[a] += (double)objects[m[k]].position[a];
+                for (int a = 0; a < 3; ++a) c[a] /= (double)n;
+                double r = 0;
+                for (int k = 0; k < n; ++k) {
+                    const srt_object& o = objects[m[k]];
+                    const double dx = (double)o.position[0] - c[0], dy = (double)o.position[1] - c[1], dz = (double)o.position[2] - c[2];
+                    r = std::max(r, sqrt(dx * dx + dy * dy + dz * dz) + fabs((double)o.radius));
+                }
+                return r * r;
+            };
+            auto size_of = [&](int c) { return (int)std::min(small.size(), (size_t)(c + 1) * (size_t)K) - c * K; };
+            std::vector<double> cost((size_t)L.nc);
+            for (int c = 0; c < L.nc; ++c) cost[(size_t)c] = radius2(&small[(size_t)c * K], size_of(c));
+            for (int pass = 0; pass < 64; ++pass) {
+                bool improved = false;
+                for (int a = 0; a < L.nc; ++a)
+                    for (int b = a + 1; b < L.nc; ++b)
+                        for (int i = 0; i < size_of(a); ++i)
+                            for (int j = 0; j < size_of(b); ++j) {
+                                int &x = small[(size_t)a * K + i], &y = small[(size_t)b * K + j];
+                                std::swap(x, y);
+                                const double ca = radius2(&small[(size_t)a * K], size_of(a)), cb = radius2(&small[(size_t)b * K], size_of(b));
+                                if (ca + cb < (cost[(size_t)a] + cost[(size_t)b]) * (1.0 - 1e-9)) {
+                                    cost[(size_t)a] = ca, cost[(size_t)b] = cb;
+                                    improved = true;
+                                } else {
+                                    std::swap(x, y);
+                                }
+                            }
+                if (!improved) break;
+            }
+        }
     }
     L.nsT = L.nu4 + L.nc * L.K;
     L.off_bounds = L.nsT;
@@ -173,8 +216,34 @@ inline SceneLayout build_scene_image(const srt_object* objects, size_t count, bo
         double C[3] = {0, 0, 0};
         for (size_t k = b; k < e; ++k)
             for (int a = 0; a < 3; ++a) C[a] += (double)objects[small[k]].position[a];
+        for (int a = 0; a < 3; ++a) C[a] /= (double)(e - b);
+        {  // a centre with a smaller enclosing radius than the centroid's, if the Badoiu-Clarkson walk finds one
+            auto radius_at = [&](const double* c) {
+                double r = 0;
+                for (size_t k = b; k < e; ++k) {
+                    const srt_object& o = objects[small[k]];
+                    const double dx = (double)o.position[0] - c[0], dy = (double)o.position[1] - c[1], dz = (double)o.position[2] - c[2];
+                    r = std::max(r, sqrt(dx * dx + dy * dy + dz * dz) + fabs((double)o.radius));
+                }
+                return r;
+            };
+            double c[3] = {C[0], C[1], C[2]}, best = radius_at(C);
+            for (int t = 1; t <= 256; ++t) {
+                size_t far = b;
+                double dfar = -1;
+                for (size_t k = b; k < e; ++k) {
+                    const srt_object& o = objects[small[k]];
+                    const double dx = (double)o.position[0] - c[0], dy = (double)o.position[1] - c[1], dz = (double)o.position[2] - c[2];
+                    const double dd = sqrt(dx * dx + dy * dy + dz * dz) + fabs((double)o.radius);
+                    if (dd > dfar) dfar = dd, far = k;
+                }
+                for (int a = 0; a < 3; ++a) c[a] += ((double)objects[small[far]].position[a] - c[a]) / (double)(t + 1);
+                const double r = radius_at(c);
+                if (r < best) best = r, C[0] = c[0], C[1] = c[1], C[2] = c[2];
+            }
+        }
         float Cf[3];
-        for (int a = 0; a < 3; ++a) Cf[a] = (float)(C[a] / (double)(e - b));
+        for (int a = 0; a < 3; ++a) Cf[a] = (float)C[a];
         double Rgeo = 0, cmax = 0;
         for (size_t k = b; k < e; ++k) {
             const srt_object& o = objects[small[k]];
