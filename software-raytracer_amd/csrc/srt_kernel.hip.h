@@ -1251,7 +1251,13 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                         continue;
                     }
                 }
-                if (__builtin_amdgcn_ballot_w64(ready) == 0ull) break;
+                const unsigned long long readym = __builtin_amdgcn_ballot_w64(ready);
+                if (readym == 0ull) break;
+                // long paths (Scene_indirect: 8 rays per sample) finish a few samples per step: a fold for fewer than a fifth of
+                // the slots waits for the next step's, unless a slot is out of ring capacity or the hand-out has ended
+                if (it == 0 && !drain && __builtin_popcountll(readym) * 5 < n_hit &&
+                    __builtin_amdgcn_ballot_w64(own_next < count && own_next >= own_done + (uint32_t)depth) == 0ull)
+                    break;
                 if (ready) {
                     if constexpr (DEFER)  // row (tile, sample) of the sample buffer: 64 slots of 16 B, coalesced
                         P.sample_rows[(tile_id * P.sample_count + s_base + own_done) * 64 + lane] = e;
