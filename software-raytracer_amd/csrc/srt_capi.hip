@@ -35,6 +35,7 @@ struct DevSwitches {
     int defer = -1;        // SRT_DEFER: 0 never chunk samples, n > 0 force n samples per chunk
     bool lpt = true;       // SRT_LPT=0: natural dispatch order
     int lpt_buckets = 128; // SRT_LPT_BUCKETS
+    int chunk_beta = 30;   // SRT_CHUNK_BETA (percent): sample chunks from recorded block costs, see srt_render
     bool host_order = true;  // SRT_HOST_ORDER=0: no host-derived initial dispatch order
     int kernel_flags = 0;    // SRT_KFLAGS: extra KernelParams.flags bits of timing experiments
 };
@@ -53,6 +54,7 @@ const DevSwitches& dev_switches() {
         d.lpt = geti("SRT_LPT", 1) != 0;
         int b = geti("SRT_LPT_BUCKETS", 128);
         d.lpt_buckets = b < 2 ? 2 : (b > 4096 ? 4096 : b);
+        d.chunk_beta = geti("SRT_CHUNK_BETA", 30);
         d.host_order = geti("SRT_HOST_ORDER", 1) != 0;
         d.kernel_flags = geti("SRT_KFLAGS", 0);
         return d;
@@ -120,6 +122,9 @@ struct srt_context {
     unsigned rec_gx = 0, rec_gy = 0;      // grid of the recording in flight
     bool recording = false;               // a cost copy is in flight (ev_cost)
     bool order_stale = true;              // scene / camera changed since the costs were recorded
+    double cost_sum = 0.0;                // of the last recorded block costs (0: none), their maximum and their grid:
+    uint32_t cost_max = 0;                //   (99.5th percentile) how uneven the blocks are decides the number of sample chunks
+    unsigned cost_gx = 0, cost_gy = 0;
     bool estimate_stale = true;           // the scene changed since the order was last estimated on the device
     bool order_disabled = false;          // buffers for the feedback could not be allocated
     hipEvent_t ev_cost = nullptr, ev_order = nullptr, ev_gather = nullptr;
@@ -361,6 +366,7 @@ static int set_scene_impl(srt_context* ctx, const srt_object* objects, size_t co
     ctx->scene_set = true;
     ctx->order_stale = true;
     ctx->estimate_stale = true;
+    ctx->cost_sum = 0.0;  // the recorded block costs describe another scene
     return SRT_OK;
 }
 
@@ -589,6 +595,22 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     // (progressive blocks, steps > 1, are traced once per block by the multi-sample instantiation: no sample chunks)
     if (tile_env == 0 && defer_env != 0 && (p->sample_count >= 64 || defer_env > 0 || K.n_tris > 0) && p->sample_count >= 32 && K.steps <= 1) {
         long long c = (96LL * ctx->cu_count + wg8 - 1) / wg8;  // about 24 k workgroups in flight over the launch
+        // With block costs recorded for this grid (an earlier launch of the frame) the number of chunks follows from how
+        // uneven the blocks are: ratio = the dearest block (99.5th percentile) over an even share of the whole launch per
+        // resident workgroup.  Well below 1 the cost order alone fills the chip — no chunks for meshes (every chunk repeats
+        // the primary hits, mesh phases included, and the colours make a round trip through the sample buffer: config 4,
+        // ratio 0.56, 10.4 -> 9.3 ms; config 5's rank-4 band, 0.80, 74 -> 69-72 ms), two for analytic scenes (finer grains
+        // at the tail: -2..-7 %).  From 0.85 on the dearest block is brought down to 0.3 of a share: config 5's rank-5 band
+        // (0.97) 245 ms unchunked, 201 with 4 chunks, 197 with 7; a 540-row band through the mesh ball (1.4-2.0) 15.7 ms
+        // unchunked, 12.1 with two, 10.8 with three, 9.9 with five.
+        if (ctx->cost_sum > 0.0 && ctx->cost_gx == (unsigned)wg_x && ctx->cost_gy == (unsigned)wg_y8) {
+            const double slots = (double)ctx->cu_count * (K.n_tris > 0 ? 3.0 : 4.0);
+            const double ratio = (double)ctx->cost_max * slots / ctx->cost_sum;
+            c = ratio < 0.85 ? (K.n_tris > 0 ? 1 : 2) : (long long)ceil(ratio * 100.0 / (double)dev_switches().chunk_beta);
+#ifdef SRT_DEV
+            if (getenv("SRT_DEBUG_CHUNKS")) fprintf(stderr, "chunks: dearest %u sum %.0f blocks %lld slots %.0f ratio %.3f -> c %lld\n", ctx->cost_max, ctx->cost_sum, wg8, slots, ratio, c);
+#endif
+        }
         if (c > p->sample_count / 16) c = p->sample_count / 16;
         if (c >= 2 || defer_env > 0) {
             chunk = (int)((p->sample_count + c - 1) / c);
@@ -687,7 +709,26 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
                 uniform = p95 <= 1.5 * p05;
             }
             uint32_t lo = 0xFFFFFFFFu, hi = 0;
-            for (size_t i = 0; i < n; ++i) lo = ctx->h_wg_cost[i] < lo ? ctx->h_wg_cost[i] : lo, hi = ctx->h_wg_cost[i] > hi ? ctx->h_wg_cost[i] : hi;
+            double sum = 0.0;
+            for (size_t i = 0; i < n; ++i) lo = ctx->h_wg_cost[i] < lo ? ctx->h_wg_cost[i] : lo, hi = ctx->h_wg_cost[i] > hi ? ctx->h_wg_cost[i] : hi, sum += (double)ctx->h_wg_cost[i];
+#ifdef SRT_DEV
+            if (getenv("SRT_DEBUG_CHUNKS")) {
+                size_t bad = 0;
+                for (size_t i = 0; i < n; ++i)
+                    if (ctx->h_wg_cost[i] > 0x40000000u) {
+                        if (bad < 6) fprintf(stderr, "cost[%zu] (bx %zu by %zu) = %u (as int %d)\n", i, i % ctx->rec_gx, i / ctx->rec_gx, ctx->h_wg_cost[i], (int)ctx->h_wg_cost[i]);
+                        ++bad;
+                    }
+                fprintf(stderr, "costs arrived: %zu blocks, %zu suspicious, grid %u x %u\n", n, bad, ctx->rec_gx, ctx->rec_gy);
+            }
+#endif
+            {  // what the sample-chunk rule looks at: the 99.5th percentile stands for the dearest block (one block's count
+               // can be inflated by whatever else the launch's first workgroups wait for)
+                std::vector<uint32_t> tmp(ctx->h_wg_cost, ctx->h_wg_cost + n);
+                const size_t k = n - 1 - n / 200;
+                std::nth_element(tmp.begin(), tmp.begin() + k, tmp.end());
+                ctx->cost_sum = sum, ctx->cost_max = tmp[k], ctx->cost_gx = ctx->rec_gx, ctx->cost_gy = ctx->rec_gy;
+            }
             const double scale = hi > lo ? (double)(NB - 1) / (double)(hi - lo) : 0.0;
             auto bucket = [&](uint32_t c) { return (NB - 1) - (int)((double)(c - lo) * scale); };
             std::vector<size_t> start((size_t)NB + 1, 0);

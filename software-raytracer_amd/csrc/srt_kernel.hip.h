@@ -1421,7 +1421,12 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
         if (lane == 0 && tot) {
             if (P.flags & 2u) atomicAdd(P.ray_counter, tot);
-            if (P.wg_cost) atomicAdd(&P.wg_cost[block_id], (uint32_t)(((long long)__builtin_readcyclecounter() - t_start) >> 8));
+            if (P.wg_cost) {
+                // (a wave whose two counter reads do not belong together — seen on some boxes as a difference of minus the
+                // launch's length, presumably a wave that was saved and restored in between — records nothing)
+                const long long dt = (long long)__builtin_readcyclecounter() - t_start;
+                if (dt > 0 && dt < (1ll << 40)) atomicAdd(&P.wg_cost[block_id], (uint32_t)(dt >> 8));
+            }
         }
     }
 }

@@ -101,14 +101,21 @@ def main():
         if os.path.exists(pj):
             doc = json.load(open(pj))
             tot = {}
+            # the kernels of the STEADY-STATE launch: the pathtrace instantiation with the most full-size dispatches (a first
+            # launch may still be sample-chunked — another instantiation plus fold_kernel — before the block costs arrive),
+            # and fold_kernel only when that instantiation is the chunked one (last template argument true)
+            cands = [kn for kn in doc["kernels"] if "pathtrace_kernel" in kn]
+            main = max(cands, key=lambda kn: doc["kernels"][kn].get("dispatches", 0)) if cands else ""
+            chunked = main.rstrip().endswith("true>")
+            steady = [main] + ([kn for kn in doc["kernels"] if "fold_kernel" in kn] if chunked else [])
             for kname, k in doc["kernels"].items():
-                if "pathtrace_kernel" in kname or "fold_kernel" in kname:
+                if kname in steady:
                     for c in ("SQ_INSTS_VALU", "hbm_bytes", "FETCH_SIZE", "WRITE_SIZE", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
                               "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_WAVES"):
                         if c in k:
                             tot[c] = tot.get(c, 0.0) + k[c]
-            entry = {"source": "profiles/%s (tools/profile_round.py -> tools/pmc_collect.py, rocprofv3 --pmc, mean per full launch, pathtrace_kernel + fold_kernel)" % rnd,
-                     "kernels": sorted(k for k in doc["kernels"] if "pathtrace_kernel" in k or "fold_kernel" in k)}
+            entry = {"source": "profiles/%s (tools/profile_round.py -> tools/pmc_collect.py, rocprofv3 --pmc, mean per full launch of the steady-state kernels)" % rnd,
+                     "kernels": sorted(steady)}
             entry.update(tot)
             if "hbm_bytes" in tot:
                 entry["hbm_bytes_per_launch"] = tot["hbm_bytes"]
