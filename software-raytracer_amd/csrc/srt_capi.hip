@@ -603,6 +603,9 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
         // at the tail: -2..-7 %).  From 0.85 on the dearest block is brought down to 0.3 of a share: config 5's rank-5 band
         // (0.97) 245 ms unchunked, 201 with 4 chunks, 197 with 7; a 540-row band through the mesh ball (1.4-2.0) 15.7 ms
         // unchunked, 12.1 with two, 10.8 with three, 9.9 with five.
+        // (no record yet: a mesh launch of >= 6000 blocks — a whole 1080p frame — starts unchunked, which is what the record
+        // of such a frame asks for; smaller ones, the bands of a multi-GPU frame, start with the workgroup-count rule above)
+        if (K.n_tris > 0 && wg8 >= 6000) c = 1;
         if (ctx->cost_sum > 0.0 && ctx->cost_gx == (unsigned)wg_x && ctx->cost_gy == (unsigned)wg_y8) {
             const double slots = (double)ctx->cu_count * (K.n_tris > 0 ? 3.0 : 4.0);
             const double ratio = (double)ctx->cost_max * slots / ctx->cost_sum;
