@@ -28,6 +28,9 @@ thread_local char g_create_error[512] = "";
 // Tuning switches.  The shipped library has none: every value below is a constant.  A development build
 // (make -C software-raytracer_amd/csrc dev -> libsrt_pathtrace_dev.so, -DSRT_DEV) reads them from the
 // environment for in-process A/B timing (tests/ab_bench.py); all settings produce identical bits.
+#ifndef SRT_ORDER_MIN_WG
+#define SRT_ORDER_MIN_WG 512  // fewest blocks of tiles for which a launch records costs and is dispatched in cost order
+#endif
 struct DevSwitches {
     int kernel = 0;        // SRT_KERNEL: tuning variant
     bool no_cluster = false;  // SRT_NO_CLUSTER
@@ -662,7 +665,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     const bool order_env = dev_switches().lpt;
     bool record = false;
     const size_t nwg = (size_t)grid.x * grid.y;
-    if (order_env && !ctx->order_disabled && nwg >= 2048 && p->sample_count >= 4 && !(p->flags & SRT_RENDER_PREVIEW) && !bgrid) {
+    if (order_env && !ctx->order_disabled && nwg >= SRT_ORDER_MIN_WG && p->sample_count >= 4 && !(p->flags & SRT_RENDER_PREVIEW) && !bgrid) {
         if (nwg > ctx->wg_capacity) {
             SRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->d_wg_cost) (void)hipFree(ctx->d_wg_cost);
@@ -690,7 +693,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             }
         }
     }
-    if (order_env && !ctx->order_disabled && ctx->wg_capacity >= nwg && nwg >= 2048 && p->sample_count >= 4 && !(p->flags & SRT_RENDER_PREVIEW) && !bgrid) {
+    if (order_env && !ctx->order_disabled && ctx->wg_capacity >= nwg && nwg >= SRT_ORDER_MIN_WG && p->sample_count >= 4 && !(p->flags & SRT_RENDER_PREVIEW) && !bgrid) {
         const hipError_t arrived = ctx->recording ? hipEventQuery(ctx->ev_cost) : hipErrorNotReady;
         if (arrived != hipSuccess) (void)hipGetLastError();  // "not ready" must not surface as this launch's error
         if (arrived == hipSuccess) {  // costs have arrived: make the order
