@@ -341,6 +341,20 @@ def test_block_grid_launches(srt, oracle, name):
     pt.close()
 
 
+@pytest.mark.parametrize("name,w,h,spp", [("Scene1", 800, 450, 6), ("Scene3", 1024, 400, 5)])
+def test_mid_size_frames_in_cost_order(srt, oracle, name, w, h, spp):
+    """Frames of 512..2048 blocks of tiles are dispatched in cost order too (first launch: the device-side estimate, later
+    launches: recorded costs): every launch gives the oracle's bits and ray count."""
+    pt, objs, n = _pt(srt, name, w, h)
+    ofb, oacc, orays = _oracle_frame(oracle, objs, n, w, h, spp=spp, bounces=8, seed=11)
+    for launch in range(4):
+        pt.render(spp=spp, bounces=8, seed=11, count_rays=True)
+        assert np.array_equal(pt.framebuffer(), ofb), launch
+        assert np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32)), launch
+        assert pt.stats().rays == orays, launch
+    pt.close()
+
+
 def test_sample_chunks_extremes(srt, oracle):
     """Sample-chunked launches at the edges: thousands of samples on a frame smaller than one workgroup
     (hundreds of chunks per tile), and a band without a single traced pixel (all sky: every tile mask 0)."""
