@@ -96,7 +96,11 @@ def scene_file_for(scene, mesh):
     tmp = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
     json.dump(sj, tmp)
     tmp.close()
+    TEMP_FILES.append(tmp.name)
     return tmp.name
+
+
+TEMP_FILES = []
 
 
 def load_json(path):
@@ -181,6 +185,11 @@ def main():
     stripes = importlib.import_module("software-raytracer_amd.stripes")
 
     scene = srt.host.Scene(scene_file_for(cfg["scene"], cfg["mesh"]))
+    for f in TEMP_FILES:  # (the mesh workloads' generated scene file: parsed, no longer needed)
+        try:
+            os.unlink(f)
+        except OSError:
+            pass
     if scene.error:
         sys.exit("scene: " + scene.error)
     objs, n_obj = scene.objects_copy()
@@ -265,8 +274,16 @@ def main():
 
     host_frame = torch.zeros((H, W), dtype=torch.int32) if rehearsal else None
 
-    def step(count_rays=False):
+    kernel_events = []  # (begin, end) HIP events on the launch stream around every TIMED step's srt_render, the gather outside
+
+    def step(count_rays=False, timed=False):
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
         pt.render(spp=spp, bounces=bounces, seed=SEED, first_sample=1, reset=True, rows=(rb, re), count_rays=count_rays)
+        if timed:
+            e1.record(stream)
+            kernel_events.append((e0, e1))
         if world == 1:
             return
         if rehearsal:  # gloo cannot move device memory: stage through the host
@@ -298,7 +315,7 @@ def main():
     t0 = time.perf_counter()
     ev0.record(stream)
     for _ in range(args.steps):
-        step()
+        step(timed=True)
     ev1.record(stream)
     fence()
     dt = time.perf_counter() - t0
@@ -308,7 +325,8 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    k_ms = stream_ms if world == 1 else last_launch_ms
+    launch_ms_mean = sum(a.elapsed_time(b) for a, b in kernel_events) / len(kernel_events)  # this rank's srt_render launches only
+    k_ms = stream_ms if world == 1 else launch_ms_mean
 
     # rays per sample (deterministic): one extra, untimed launch with the counter on
     step(count_rays=True)
@@ -354,24 +372,37 @@ def main():
     if rank == 0:
         rbar = sum(p[1] for p in per_rank) / sum(p[2] for p in per_rank)
         key = workload_key(cfg["scene"], cfg["mesh"], W, H, (rb, re), spp, bounces)
-        counters = load_json(os.path.join(ROOT, "profiles", "counters.json")).get(key, {}) if world == 1 else {}
-        mesh_counts = load_json(os.path.join(ROOT, "profiles", "mesh_counts.json")).get(key, {}) if n_tri else {}
-        node_items = mesh_counts.get("node_items_per_sample", 0.0)
-        tri_tests = mesh_counts.get("triangle_tests_per_sample", 0.0)
-        f_sample = algorithmic_laneops_per_sample(rbar_local, n_sph, n_box, node_items, tri_tests)
-        achieved_valu = f_sample * local_samples / (k_ms * 1e-3)
+        all_counters = load_json(os.path.join(ROOT, "profiles", "counters.json"))
+        all_mesh_counts = load_json(os.path.join(ROOT, "profiles", "mesh_counts.json")) if n_tri else {}
+        counters = all_counters.get(key, {}) if world == 1 else {}
+        rank_rows = [tuple(bands[i]) if not share else (rb, re) for i in range(len(per_rank))]
+        # lane-ops of every rank's launch (SURVEY §8d formula with that rank's own rays per sample; mesh scenes: + the counted
+        # BVH work of that rank's band from profiles/mesh_counts.json), then: one rank -> its launch; N ranks -> the sum of all
+        # ranks' lane-ops over the SLOWEST rank's launch time against N GPUs' peak, with every rank's own fraction in per_rank
+        uncounted = False
+        rank_ops, rank_f = [], []
+        for (k_i, rays_i, samples_i), rows_i in zip(per_rank, rank_rows):
+            mc = all_mesh_counts.get(workload_key(cfg["scene"], cfg["mesh"], W, H, rows_i, spp, bounces), {}) if n_tri else {}
+            uncounted = uncounted or (bool(n_tri) and not mc)
+            f_i = algorithmic_laneops_per_sample(rays_i / samples_i, n_sph, n_box, mc.get("node_items_per_sample", 0.0), mc.get("triangle_tests_per_sample", 0.0))
+            rank_f.append(f_i)
+            rank_ops.append(f_i * samples_i)
+        slowest_ms = max(p[0] for p in per_rank)
+        achieved_valu = sum(rank_ops) / (slowest_ms * 1e-3)
+        peak_valu = VALU_PEAK_LANEOPS * len(per_rank)
         abytes = algorithmic_bytes(W, re - rb, n_obj, resume=False)
         abytes += 32 * traced_samples  # sample-chunked launch: + 16 B written and 16 B read per traced sample (the fold's stream)
         achieved_gbs = abytes / (k_ms * 1e-3) / 1e9
-        if n_tri and not mesh_counts:
+        if uncounted:
             kind = "UNCOUNTED: no profiles/mesh_counts.json entry for this workload; the BVH work is missing from `achieved`"
         elif n_tri:
             kind = "counted: analytic part by the SURVEY §8d formula + BVH node items x %d + triangle tests x %d (profiles/mesh_counts.json)" % (NODE_OPS, TRI_OPS)
         else:
             kind = "brute-force-equivalent lane-ops of the SURVEY §8d formula (the kernel culls: algorithmic throughput, not pipe utilisation)"
-        measured_issue = None
-        if counters.get("SQ_INSTS_VALU"):
-            measured_issue = counters["SQ_INSTS_VALU"] * 64 / (k_ms * 1e-3) / VALU_PEAK_LANEOPS
+        if world > 1:
+            kind += "; N = %d: sum of all ranks' lane-ops / the slowest rank's launch time, peak = %d GPUs" % (world, world)
+        # pipe utilisation: computed INSIDE the counter pass (its own SQ_INSTS_VALU over its own launch time), copied from profiles
+        measured_issue = counters.get("valu_issue_frac")
         custom = any(getattr(args, k) is not None for k in ("scene", "width", "height", "spp", "bounces", "mesh"))
         what = "custom workload (config %d with overrides)" % cfg_id if custom else "config %d" % cfg_id
         if world > 1 and not args.config and not custom:
@@ -387,7 +418,9 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            # per-GPU work fixed as N grows (the default N > 1 sequence: 64 spp per GPU-share) -> weak; a BASELINE config in
+            # its stated form holds the frame AND the samples fixed -> strong
+            "scaling": "strong" if (args.config and world > 1) else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (shipped %s.json scene%s, counter-based RNG seed 0)" %
@@ -407,21 +440,26 @@ def main():
             "roofline": {
                 "bound": "valu",
                 "achieved": achieved_valu / 1e12,
-                "peak": VALU_PEAK_LANEOPS / 1e12,
+                "peak": peak_valu / 1e12,
                 "unit": "TFLOP/s",
-                "frac": achieved_valu / VALU_PEAK_LANEOPS,
+                "frac": achieved_valu / peak_valu,
                 "traffic": counters.get("hbm_bytes_per_launch"),
                 "kernel": "srt::pathtrace_kernel" + (" + srt::fold_kernel (%d sample chunks)" % chunks if chunks > 1 else ""),
-                "kernel_ms": k_ms,
+                "kernel_ms": slowest_ms,
                 "kernel_ms_source": "HIP events on the launch stream around the %d timed steps / %d" % (args.steps, args.steps)
-                                    if world == 1 else "the library's event pair around the last timed launch",
+                                    if world == 1 else "the SLOWEST rank's mean over the HIP event pairs around each timed step's srt_render (the gather outside); all ranks in per_rank",
                 "kernel_ms_last_timed_launch": last_launch_ms,
                 "kernel_ms_cold_first_launch": cold_ms,
-                "peak_note": "fp32 VALU without FMA credit: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (contraction is forbidden by the bit-exactness contract)",
+                "peak_note": "%sfp32 VALU without FMA credit: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (contraction is forbidden by the bit-exactness contract)" %
+                             ("%d GPUs x " % world if world > 1 else ""),
                 "achieved_kind": kind,
-                "algorithmic_laneops_per_sample": f_sample,
-                "rays_per_sample": rbar_local,
+                "algorithmic_laneops_per_sample": sum(rank_ops) / sum(p[2] for p in per_rank),
+                "rays_per_sample": rbar,
                 "measured_valu_issue_frac": measured_issue,
+                "measured_valu_issue_frac_note": "from profiles/counters.json, NOT from this run: SQ_INSTS_VALU x 64 / the launch time of the rocprofv3 pass "
+                                                 "that counted it / peak (valu_issue_pass_launch_ms); clock-independent twin: measured_valu_issue_frac_grbm" if measured_issue else None,
+                "measured_valu_issue_frac_grbm": counters.get("valu_issue_frac_grbm"),
+                "measured_pass_launch_ms": counters.get("valu_issue_pass_launch_ms"),
                 "measured_source": counters.get("source"),
             },
             "roofline_hbm": {
@@ -435,8 +473,8 @@ def main():
                 "note": "compulsory bytes only (20 B/pixel + scene%s); not the limiting resource" %
                         (" + 32 B per traced sample of the chunked launch's sample buffer" if chunks > 1 else ""),
             },
-            "per_rank": [{"kernel_ms": p[0], "rays_per_sample": p[1] / p[2], "rows": list(bands[i] if not share else (rb, re))}
-                         for i, p in enumerate(per_rank)],
+            "per_rank": [{"kernel_ms": p[0], "rays_per_sample": p[1] / p[2], "rows": list(rank_rows[i]), "algorithmic_laneops": rank_ops[i],
+                          "frac": rank_ops[i] / (p[0] * 1e-3) / VALU_PEAK_LANEOPS} for i, p in enumerate(per_rank)],
         }
         if calibration:
             out["config"].update(calibration)

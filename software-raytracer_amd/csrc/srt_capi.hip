@@ -131,6 +131,7 @@ struct srt_context {
     bool estimate_stale = true;           // the scene changed since the order was last estimated on the device
     bool order_disabled = false;          // buffers for the feedback could not be allocated
     hipEvent_t ev_cost = nullptr, ev_order = nullptr, ev_gather = nullptr;
+    unsigned long long peer_enabled = 0;  // srt_gather_band: destination devices this context's device has peer access enabled for
 
     srt_environment env;
     HostCamera camera;
@@ -370,6 +371,10 @@ static int set_scene_impl(srt_context* ctx, const srt_object* objects, size_t co
     ctx->order_stale = true;
     ctx->estimate_stale = true;
     ctx->cost_sum = 0.0;  // the recorded block costs describe another scene
+    // ... and so does a cost copy that may still be in flight, and the dispatch order made from the old scene's costs: both are
+    // dropped (the stream was synchronised above, so nothing still writes h_wg_cost), the next launch estimates afresh
+    ctx->recording = false;
+    ctx->order_gx = ctx->order_gy = 0;
     return SRT_OK;
 }
 
@@ -992,19 +997,31 @@ int srt_gather_band(srt_context* dst, srt_context* src, int row_begin, int row_e
         return fail(dst, SRT_ERR_INVALID_ARG, "srt_gather_band: bad rows [%d,%d)", row_begin, row_end);
     if (dst == src) return SRT_OK;
     const size_t rowb = (size_t)src->width * 4, off = (size_t)row_begin * rowb, bytes = (size_t)(row_end - row_begin) * rowb;
-    SRT_HIP(dst, hipSetDevice(src->device));
-    if (src->device != dst->device) {
-        // direct xGMI path where the topology offers it; without peer access the runtime stages the copy
-        const hipError_t pe = hipDeviceEnablePeerAccess(dst->device, 0);
-        if (pe != hipSuccess) (void)hipGetLastError();  // already enabled, or not available: both fine
-        SRT_HIP(dst, hipMemcpyPeerAsync((char*)dst->d_fb + off, dst->device, (const char*)src->d_fb + off, src->device, bytes, src->stream));
-    } else {
-        SRT_HIP(dst, hipMemcpyAsync((char*)dst->d_fb + off, (const char*)src->d_fb + off, bytes, hipMemcpyDeviceToDevice, src->stream));
+    // every HIP call below runs with the SOURCE's device current; whatever happens, the caller gets the destination's
+    // device back (a failure must not leave the thread on another GPU)
+    hipError_t e = hipSetDevice(src->device);
+    const char* what = "hipSetDevice";
+    if (e == hipSuccess && src->device != dst->device) {
+        // direct xGMI path where the topology offers it (enabled once per pair of devices and source context); without peer
+        // access the runtime stages the copy.  NOTE: this branch needs two GPUs and has never executed on this project's
+        // one-GPU boxes — it is unverified code.
+        if (dst->device < 64 && !((src->peer_enabled >> dst->device) & 1ull)) {
+            const hipError_t pe = hipDeviceEnablePeerAccess(dst->device, 0);
+            if (pe != hipSuccess) (void)hipGetLastError();  // already enabled, or not available: both fine
+            src->peer_enabled |= 1ull << dst->device;
+        }
+        what = "hipMemcpyPeerAsync";
+        e = hipMemcpyPeerAsync((char*)dst->d_fb + off, dst->device, (const char*)src->d_fb + off, src->device, bytes, src->stream);
+    } else if (e == hipSuccess) {
+        what = "hipMemcpyAsync";
+        e = hipMemcpyAsync((char*)dst->d_fb + off, (const char*)src->d_fb + off, bytes, hipMemcpyDeviceToDevice, src->stream);
     }
-    if (!src->ev_gather) SRT_HIP(dst, hipEventCreateWithFlags(&src->ev_gather, hipEventDisableTiming));
-    SRT_HIP(dst, hipEventRecord(src->ev_gather, src->stream));
-    SRT_HIP(dst, hipSetDevice(dst->device));
-    SRT_HIP(dst, hipStreamWaitEvent(dst->stream, src->ev_gather, 0));
+    if (e == hipSuccess && !src->ev_gather) what = "hipEventCreate", e = hipEventCreateWithFlags(&src->ev_gather, hipEventDisableTiming);
+    if (e == hipSuccess) what = "hipEventRecord", e = hipEventRecord(src->ev_gather, src->stream);
+    const hipError_t back = hipSetDevice(dst->device);
+    if (e == hipSuccess) what = "hipSetDevice", e = back;
+    if (e == hipSuccess) what = "hipStreamWaitEvent", e = hipStreamWaitEvent(dst->stream, src->ev_gather, 0);
+    if (e != hipSuccess) return fail(dst, e == hipErrorOutOfMemory ? SRT_ERR_OOM : SRT_ERR_HIP, "srt_gather_band: %s: %s", what, hipGetErrorString(e));
     return SRT_OK;
 }
 

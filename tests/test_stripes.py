@@ -44,7 +44,7 @@ WORKER = textwrap.dedent('''
     st = importlib.import_module("software-raytracer_amd.stripes")
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo")
-    W, H = 96, 54
+    W, H = 96, (54 if world == 2 else 7 * world)  # equal bands divide exactly -> the in-place dist.gather
     objs = O.load_scene_json_py(os.path.join({root!r}, "software-raytracer_amd", "scenes", "Scene_indirect.json"))
     arr, n = O.make_objects(objs)
     env, cam = O.default_environment(), O.default_camera()
@@ -65,7 +65,7 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-def test_two_rank_gloo_gather_equals_single_frame(tmp_path, oracle):
+def _run_ranks(tmp_path, world, timeout):
     script = tmp_path / "w.py"
     script.write_text(WORKER.format(root=ROOT))
     s = socket.socket()
@@ -73,8 +73,21 @@ def test_two_rank_gloo_gather_equals_single_frame(tmp_path, oracle):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
-                         capture_output=True, text=True, timeout=300, env=env)
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                          capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_two_rank_gloo_gather_equals_single_frame(tmp_path, oracle):
+    out = _run_ranks(tmp_path, 2, 300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("OK") == 3, out.stdout + out.stderr
+
+
+def test_eight_rank_gloo_gather_equals_single_frame(tmp_path, oracle):
+    """The shape of the driver's N = 8 run (one process per rank, ONE gather to rank 0), on CPU over gloo with the oracle as
+    renderer: equal bands (8 x 7 rows, received in place by ONE dist.gather — the default of north_star), cost-balanced bands joined in place
+    (p2p) and joined by one dist.gather of bands padded to the tallest (what bench.py does for unequal bands)."""
+    out = _run_ranks(tmp_path, 8, 600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("OK") == 3, out.stdout + out.stderr

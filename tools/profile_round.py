@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Regenerates profiles/<round>/ and profiles/{counters,mesh_counts}.json on the GPU box.
 
-usage (through gpurun, from the repo root):  python3 tools/profile_round.py r02 [--only c2,c4,...]
+usage (through gpurun, from the repo root):  python3 tools/profile_round.py r03 [--only c2,c4,...]
 
 For every workload below:
   profiles/<round>/bench_<name>.json         the bench.py line (roofline, roofline_hbm, cpu_baseline where it applies)
@@ -9,7 +9,9 @@ For every workload below:
   profiles/counters.json[workload_key]       PMC counters per FULL launch of the workload, one counter group per pass
                                              (tools/pmc_collect.py: never together with a trace domain; FETCH_SIZE and
                                              WRITE_SIZE in passes of their own), summed over the launch's kernels
-                                             (pathtrace_kernel + fold_kernel for sample-chunked launches):
+                                             (pathtrace_kernel + fold_kernel for sample-chunked launches); the TIMED launches are
+                                             picked by position (tools/dispatches.py), every fraction is computed with the
+                                             launch time of the pass the counter came from (stored next to it):
                                              SQ_INSTS_VALU, hbm_bytes_per_launch = FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024
                                              (gfx950: FETCH_SIZE reports half of a wide streaming read, MI355X_MICROARCH.md)
   profiles/mesh_counts.json[workload_key]    mesh workloads: BVH node items and triangle tests per path-sample, counted by
@@ -21,16 +23,22 @@ import glob
 import json
 import os
 import re
+import shutil
 import subprocess
 import sys
 
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import dispatches as D  # noqa: E402
 WORKLOADS = [  # name, bench.py arguments, mesh tessellation
     ("c2", [], 0),
-    ("c3_rank4of8", ["--config", "3", "--rank", "4/8"], 0),
-    ("c3_rank7of8", ["--config", "3", "--rank", "7/8"], 0),
+    ("c3_rank0of8", ["--config", "3", "--rank", "0/8", "--balance", "equal"], 0),
+    ("c3_rank4of8", ["--config", "3", "--rank", "4/8", "--balance", "equal"], 0),
+    ("c3_rank7of8", ["--config", "3", "--rank", "7/8", "--balance", "equal"], 0),
+    ("c3_rank4of8_probe", ["--config", "3", "--rank", "4/8", "--balance", "probe"], 0),
     ("c4", ["--config", "4"], 224),
-    ("c5_rank4of8", ["--config", "5", "--rank", "4/8", "--steps", "3", "--warmup", "1"], 224),
+    ("c5_rank4of8", ["--config", "5", "--rank", "4/8", "--balance", "equal", "--steps", "3", "--warmup", "2"], 224),
+    ("c5_rank5of8", ["--config", "5", "--rank", "5/8", "--balance", "equal", "--steps", "3", "--warmup", "2"], 224),
     ("scene_indirect", ["--scene", "Scene_indirect"], 0),
 ]
 
@@ -67,63 +75,43 @@ def main():
         print(name, key, "%.4g samples/s" % line["value"], flush=True)
         # 2. kernel trace + stats of the same command
         d = os.path.join(scratch, "trace_" + name)
+        shutil.rmtree(d, ignore_errors=True)
         r = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", os.path.join(ROOT, "bench.py")] + args + steps +
                 ["--no-cpu-baseline"], cwd="/tmp", env=env, timeout=900)
         st = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)
         if st:
             open(os.path.join(out, "kernel_stats_%s.csv" % name), "w").write(open(st[0]).read())
-        # the same trace, FULL-SIZE dispatches only (largest grid per kernel): bench.py's 8-row priming launch and
-        # its 1-bounce probe would otherwise dilute the averages of kernel_stats.csv
+        # the same trace, launch by launch (tools/dispatches.py): the TIMED launches are picked by position — after the priming
+        # launch and the warm-up steps — whatever their grid, so a sample-chunked frame's steady state (fewer chunks than its
+        # cold launches) is what gets summarised; priming / warm-up / post launches are listed apart
         tr = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)
         if tr:
-            import csv
-
-            per = {}
-            for row in csv.DictReader(open(tr[0])):
-                if "srt::" not in row["Kernel_Name"]:
-                    continue
-                grid = 1
-                for ax in "XYZ":
-                    grid *= int(row.get("Grid_Size_" + ax, 1) or 1)
-                kn = row["Kernel_Name"].split("(")[0].replace("void ", "")
-                per.setdefault(kn, []).append((grid, (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6))
-            dur = {}
-            for kn, v in per.items():
-                g = max(x[0] for x in v)
-                ms = [x[1] for x in v if x[0] == g]
-                dur[kn] = {"grid_threads": g, "calls": len(ms), "mean_ms": sum(ms) / len(ms), "min_ms": min(ms), "max_ms": max(ms),
-                           "first_ms": ms[0], "dropped_smaller_dispatches": len(v) - len(ms)}
+            n_warm, n_steps = D.bench_arg(args + steps, "--warmup", 2), D.bench_arg(args + steps, "--steps", 10)
+            parts = D.classify(D.group_launches(D.read_kernel_trace(tr[0])), n_warm, n_steps)
+            dur = {"selection": "by position: launch 0 priming, 1..%d warm-up, then %d timed, rest post (ray count, probes)" % (n_warm, n_steps),
+                   "timed": D.summarise(parts["timed"]), "warmup": [D.describe(l) for l in parts["warmup"]],
+                   "priming": [D.describe(l) for l in parts["priming"]], "post": [D.describe(l) for l in parts["post"]]}
             json.dump(dur, open(os.path.join(out, "kernel_durations_%s.json" % name), "w"), indent=1, sort_keys=True)
-        # 3. counters, one group per pass
-        r = run([sys.executable, os.path.join(ROOT, "tools", "pmc_collect.py"), "profile_%s/pmc_%s" % (rnd, name), "--groups", "hbm_r,hbm_w,sq1,sq2", "--"] + args +
-                ["--steps", "3", "--warmup", "2"], cwd=ROOT, timeout=1500)
+        # 3. counters, one group per pass; timed launches by position, every ratio with the duration of its own pass
+        pmc_steps = ["--steps", "3", "--warmup", "3"]
+        r = run([sys.executable, os.path.join(ROOT, "tools", "pmc_collect.py"), "profile_%s/pmc_%s" % (rnd, name), "--groups", "hbm_r,hbm_w,sq1,sq2", "--"] +
+                [a for i, a in enumerate(args) if a not in ("--steps", "--warmup") and (i == 0 or args[i - 1] not in ("--steps", "--warmup"))] + pmc_steps, cwd=ROOT, timeout=2400)
         pj = os.path.join(scratch, "pmc_" + name, "pmc.json")
         if os.path.exists(pj):
             doc = json.load(open(pj))
-            tot = {}
-            # the kernels of the STEADY-STATE launch: the pathtrace instantiation with the most full-size dispatches (a first
-            # launch may still be sample-chunked — another instantiation plus fold_kernel — before the block costs arrive),
-            # and fold_kernel only when that instantiation is the chunked one (last template argument true)
-            cands = [kn for kn in doc["kernels"] if "pathtrace_kernel" in kn]
-            main = max(cands, key=lambda kn: doc["kernels"][kn].get("dispatches", 0)) if cands else ""
-            chunked = main.rstrip().endswith("true>")
-            steady = [main] + ([kn for kn in doc["kernels"] if "fold_kernel" in kn] if chunked else [])
-            for kname, k in doc["kernels"].items():
-                if kname in steady:
-                    for c in ("SQ_INSTS_VALU", "hbm_bytes", "FETCH_SIZE", "WRITE_SIZE", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
-                              "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_WAVES"):
-                        if c in k:
-                            tot[c] = tot.get(c, 0.0) + k[c]
-            entry = {"source": "profiles/%s (tools/profile_round.py -> tools/pmc_collect.py, rocprofv3 --pmc, mean per full launch of the steady-state kernels)" % rnd,
-                     "kernels": sorted(steady)}
-            entry.update(tot)
-            if "hbm_bytes" in tot:
-                entry["hbm_bytes_per_launch"] = tot["hbm_bytes"]
-            if "GRBM_GUI_ACTIVE" in tot and "SQ_WAVE_CYCLES" in tot:
-                entry["waves_per_cu"] = tot["SQ_WAVE_CYCLES"] * 4 / (tot["GRBM_GUI_ACTIVE"] / 8 * 256)
+            k = doc.get("timed", {})
+            entry = {"source": "profiles/%s/pmc_%s.json (tools/profile_round.py -> tools/pmc_collect.py: rocprofv3 --pmc, one group per pass, mean per TIMED "
+                               "launch of bench.py picked by position; every fraction uses the launch time of the pass its counter came from)" % (rnd, name),
+                     "kernels": sorted({kn for p in doc.get("passes", {}).values() for kn in p.get("kernels", {})}),
+                     "pass_launch_ms": {g: p["launch_ms_mean"] for g, p in doc.get("passes", {}).items()}}
+            for c, v in k.items():
+                if not c.endswith("__pass"):
+                    entry[c] = v
+            if "hbm_bytes" in k:
+                entry["hbm_bytes_per_launch"] = k["hbm_bytes"]
             counters[key] = entry
             json.dump(counters, open(cpath, "w"), indent=1, sort_keys=True)
-            open(os.path.join(out, "pmc_%s.json" % name), "w").write(json.dumps(doc, indent=1))
+            open(os.path.join(out, "pmc_%s.json" % name), "w").write(json.dumps(doc, indent=1, sort_keys=True))
         else:
             print(name, "pmc failed:", r.stdout[-300:], r.stderr[-300:])
         # 4. mesh workloads: counted BVH work per path-sample (STATS=1 development library; per-sample figures do not
