@@ -144,7 +144,14 @@ def load_library():
     if not os.path.exists(_LIB):
         raise SrtError(ERR_STATE, "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                   "or `make -C software-raytracer_amd/csrc` (there is no fallback path)" % _LIB)
-    L = C.CDLL(_LIB)
+    _lib = open_library(_LIB)
+    return _lib
+
+
+def open_library(path):
+    """dlopen one build of the C-ABI library and declare its prototypes (load_library() for the product's; development
+    tools open several builds side by side for interleaved A/B timing, tests/ab_libs.py)."""
+    L = C.CDLL(path)
     ctx = C.c_void_p
     L.srt_abi_version.restype = C.c_int
     L.srt_device_count.argtypes = [C.POINTER(C.c_int)]
@@ -175,7 +182,6 @@ def load_library():
         fn = getattr(L, name)
         if name != "srt_last_error":
             fn.restype = C.c_int
-    _lib = L
     return L
 
 
@@ -205,8 +211,8 @@ def default_camera(fov=55):
 class PathTracer:
     """Thin RAII wrapper of an srt_context handle."""
 
-    def __init__(self, width, height, device=0):
-        self.L = load_library()
+    def __init__(self, width, height, device=0, lib=None):
+        self.L = lib if lib is not None else load_library()
         self.width, self.height = int(width), int(height)
         self._h = C.c_void_p()
         rc = self.L.srt_create(int(device), self.width, self.height, C.byref(self._h))

@@ -41,6 +41,7 @@ struct DevSwitches {
     int chunk_beta = 30;   // SRT_CHUNK_BETA (percent): sample chunks from recorded block costs, see srt_render
     bool host_order = true;  // SRT_HOST_ORDER=0: no host-derived initial dispatch order
     int kernel_flags = 0;    // SRT_KFLAGS: extra KernelParams.flags bits of timing experiments
+    bool one_kernel = true;  // SRT_ONE=0: one-sample launches through the pool kernel (A/B aid)
 };
 #ifdef SRT_DEV
 const DevSwitches& dev_switches() {
@@ -60,6 +61,7 @@ const DevSwitches& dev_switches() {
         d.chunk_beta = geti("SRT_CHUNK_BETA", 30);
         d.host_order = geti("SRT_HOST_ORDER", 1) != 0;
         d.kernel_flags = geti("SRT_KFLAGS", 0);
+        d.one_kernel = geti("SRT_ONE", 1) != 0;
         return d;
     }();
     return sw;
@@ -128,6 +130,7 @@ struct srt_context {
     double cost_sum = 0.0;                // of the last recorded block costs (0: none), their maximum and their grid:
     uint32_t cost_max = 0;                //   (99.5th percentile) how uneven the blocks are decides the number of sample chunks
     unsigned cost_gx = 0, cost_gy = 0;
+    int band_y0 = -1, band_rows = -1;     // the row band the order, the recording and the cost figures above belong to
     bool estimate_stale = true;           // the scene changed since the order was last estimated on the device
     bool order_disabled = false;          // buffers for the feedback could not be allocated
     hipEvent_t ev_cost = nullptr, ev_order = nullptr, ev_gather = nullptr;
@@ -140,6 +143,7 @@ struct srt_context {
     uint64_t pending_samples = 0;
     uint32_t pending_chunks = 1;
     bool count_rays = false;
+    int one_parity = 0;  // which of the two work counters the next one-sample launch counts on
     int lds_limit_bytes = 64 * 1024;
     int cu_count = 256;
     bool scene_in_lds[2] = {true, true};  // per scene image: does it fit into LDS next to the scratch?
@@ -243,7 +247,10 @@ int srt_create(int device, int width, int height, srt_context** out) {
     const size_t px = (size_t)width * height;
     if ((e = hipMalloc((void**)&ctx->d_fb_own, px * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc framebuffer");
     if ((e = hipMalloc((void**)&ctx->d_acc_own, px * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc accumulator");
-    if ((e = hipMalloc((void**)&ctx->d_rays, sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc counter");
+    // [0] ray counter (SRT_RENDER_COUNT_RAYS), [1] the two work counters of the one-sample streaming kernel (zeroed here once; every
+    // launch uses one and leaves the other zeroed for the next launch, so no memset precedes a 0.15 ms kernel)
+    if ((e = hipMalloc((void**)&ctx->d_rays, 2 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc counter");
+    if ((e = hipMemsetAsync(ctx->d_rays, 0, 2 * sizeof(unsigned long long), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
     if ((e = hipMalloc((void**)&ctx->d_pick, 4 * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc pick");
     if ((e = hipMemsetAsync(ctx->d_fb_own, 0, px * sizeof(uint32_t), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
     if ((e = hipMemsetAsync(ctx->d_acc_own, 0, px * sizeof(float4), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
@@ -510,6 +517,7 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
     const srt::SceneLayout& SL = ctx->layout[img];
     K.nu4 = SL.nu4;
     K.nu = SL.nu;
+    K.cluster_c1max = SL.cluster_c1max;
     K.nc = SL.nc;
     K.K = SL.K;
     K.nsT = SL.nsT;
@@ -562,6 +570,50 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     fill_kernel_params(ctx, p, K, lds_bytes, use, img);
     ctx->count_rays = (p->flags & SRT_RENDER_COUNT_RAYS) != 0;
     if (ctx->count_rays) SRT_HIP(ctx, hipMemsetAsync(ctx->d_rays, 0, sizeof(unsigned long long), ctx->stream));
+    // The learned dispatch order, a cost copy in flight and the cost figures of the chunk rule describe ONE row band.  Another
+    // band of the same height has the same grid but other blocks behind every index: it starts from a fresh estimate, like a new
+    // scene.  (Found the hard way: a 270-row band of config 5 launched after its neighbour inherited "no sample chunks" and
+    // ran 46 ms instead of 12.)
+    if (K.y0 != ctx->band_y0 || K.rows != ctx->band_rows) {
+        ctx->band_y0 = K.y0, ctx->band_rows = K.rows;
+        ctx->order_stale = ctx->estimate_stale = true;
+        ctx->cost_sum = 0.0;
+        ctx->recording = false;
+        ctx->order_gx = ctx->order_gy = 0;
+    }
+
+    // One sample per pixel at full resolution — the reference's own frame loop (Raytracer.cpp:572-595: every frame adds one
+    // sample) — runs the streaming kernel: resident waves pull 32 x 8 pixel chunks from a device counter and keep all 64 lanes
+    // on live paths until the launch runs out of pixels (srt_kernel.hip.h, pathtrace_one_kernel).  Same bits as the pool kernel.
+    if (p->sample_count == 1 && K.steps <= 1 && !(K.flags & SRT_RENDER_PREVIEW) && dev_switches().one_kernel) {
+        K.tile_h = srt::TILE_H;
+        const long long n_chunks = (long long)((W + srt::ONE_CHUNK_W - 1) / srt::ONE_CHUNK_W) * ((K.rows + srt::ONE_CHUNK_H - 1) / srt::ONE_CHUNK_H);
+        const int per_cu = K.n_tris > 0 ? 3 : 4;  // workgroups a CU holds (launch bounds + LDS)
+        const int waves_per_wg = srt::WG_TILES_X * srt::WG_TILES_Y;
+        long long wgs = (n_chunks + waves_per_wg - 1) / waves_per_wg;  // no more waves than chunks
+        if (wgs > (long long)per_cu * ctx->cu_count) wgs = (long long)per_cu * ctx->cu_count;
+        // launches of a context are ordered (one stream at a time): this one counts on counter `one_parity` and zeroes the other
+        unsigned* d_work = reinterpret_cast<unsigned*>(ctx->d_rays + 1) + ctx->one_parity;
+        unsigned* d_work_next = reinterpret_cast<unsigned*>(ctx->d_rays + 1) + (ctx->one_parity ^ 1);
+        ctx->one_parity ^= 1;
+        SRT_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
+        const dim3 g1((unsigned)wgs), b1(srt::WG_THREADS);
+        const bool lds1 = ctx->scene_in_lds[img];
+        if (K.n_tris > 0) {
+            if (lds1) hipLaunchKernelGGL((srt::pathtrace_one_kernel<3, true, true>), g1, b1, lds_bytes, ctx->stream, K, d_work, d_work_next);
+            else hipLaunchKernelGGL((srt::pathtrace_one_kernel<3, true, false>), g1, b1, lds_bytes, ctx->stream, K, d_work, d_work_next);
+        } else {
+            if (lds1) hipLaunchKernelGGL((srt::pathtrace_one_kernel<4, false, true>), g1, b1, lds_bytes, ctx->stream, K, d_work, d_work_next);
+            else hipLaunchKernelGGL((srt::pathtrace_one_kernel<4, false, false>), g1, b1, lds_bytes, ctx->stream, K, d_work, d_work_next);
+        }
+        SRT_HIP(ctx, hipGetLastError());
+        SRT_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
+        ctx->launched = true;
+        ctx->stats_pending = true;
+        ctx->pending_samples = (uint64_t)W * (uint64_t)K.rows;
+        ctx->pending_chunks = 1;
+        return SRT_OK;
+    }
 
     // Tile height: with few rows and many samples per pixel (a narrow stripe of a multi-GPU frame) 8-row
     // tiles give too few workgroups to fill 256 CUs x 4 resident workgroups and leave nothing to balance
@@ -760,9 +812,9 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             const size_t image_bytes = (size_t)(K.scene_vec4 > 0 ? K.scene_vec4 : 1) * sizeof(float4);
             const size_t est_lds = (ctx->pick_in_lds[img] ? image_bytes : 0) + srt::WAVE_SCRATCH_BYTES + srt::MESH_WAVE_BYTES;
             if (ctx->pick_in_lds[img])
-                hipLaunchKernelGGL(srt::block_cost_kernel<true>, dim3((unsigned)((nwg + 3) / 4)), dim3(64), est_lds, ctx->stream, K, ctx->d_wg_est, (int)grid.x, (int)nwg, (uint32_t*)nullptr);
+                hipLaunchKernelGGL(srt::block_cost_kernel<true>, dim3((unsigned)((nwg + 3) / 4)), dim3(64), est_lds, ctx->stream, K, ctx->d_wg_est, (int)grid.x, (int)nwg, (uint32_t*)nullptr, (uint32_t*)nullptr);
             else
-                hipLaunchKernelGGL(srt::block_cost_kernel<false>, dim3((unsigned)((nwg + 3) / 4)), dim3(64), est_lds, ctx->stream, K, ctx->d_wg_est, (int)grid.x, (int)nwg, (uint32_t*)nullptr);
+                hipLaunchKernelGGL(srt::block_cost_kernel<false>, dim3((unsigned)((nwg + 3) / 4)), dim3(64), est_lds, ctx->stream, K, ctx->d_wg_est, (int)grid.x, (int)nwg, (uint32_t*)nullptr, (uint32_t*)nullptr);
             hipLaunchKernelGGL(srt::smooth_cost_kernel, dim3((unsigned)((nwg + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_wg_est, ctx->d_wg_est + nwg, (int)nwg, (int)grid.x);
             hipLaunchKernelGGL(srt::order_sort_kernel, dim3(1), dim3(srt::ORDER_SORT_THREADS), 0, ctx->stream, ctx->d_wg_est + nwg, ctx->d_wg_order, (int)nwg);
             if (hipGetLastError() == hipSuccess) {
@@ -849,6 +901,14 @@ int srt_debug_read_stats(unsigned long long* out8) {
     unsigned long long z[8] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(srt::g_stats), z, sizeof z);
     return e == hipSuccess ? 0 : 3;
+}
+#endif
+
+#if defined(SRT_STATS) && SRT_STATS == 6
+int srt_debug_read_wave_log(unsigned long long* out, size_t waves) {
+    (void)hipDeviceSynchronize();
+    if (waves > (size_t)srt::WAVE_LOG_MAX) waves = srt::WAVE_LOG_MAX;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(srt::g_wave_log), waves * 6 * sizeof(unsigned long long)) == hipSuccess ? 0 : 3;
 }
 #endif
 
@@ -949,11 +1009,9 @@ int srt_read_accumulator(srt_context* ctx, float* dst_rgba) {
     return SRT_OK;
 }
 
-int srt_estimate_row_costs(srt_context* ctx, int max_bounces, uint32_t seed, float* row_costs) {
-    if (!ctx || !row_costs) return SRT_ERR_INVALID_ARG;
-    if (!ctx->scene_set) return fail(ctx, SRT_ERR_STATE, "srt_estimate_row_costs: srt_set_scene has not been called");
-    if (!ctx->camera.set) return fail(ctx, SRT_ERR_STATE, "srt_estimate_row_costs: srt_set_camera has not been called");
-    if (max_bounces < 0) return fail(ctx, SRT_ERR_INVALID_ARG, "srt_estimate_row_costs: max_bounces must be >= 0");
+// the device-side probe of block_cost_kernel over the WHOLE frame: per 16 x 16 block its balance cost and, for the development
+// library's fitting tool, the raw feature sums (8 words per block)
+static int run_block_probe(srt_context* ctx, int max_bounces, uint32_t seed, std::vector<uint32_t>& balance, std::vector<uint32_t>* features, int& bx, int& by) {
     SRT_HIP(ctx, hipSetDevice(ctx->device));
     const int W = ctx->width, H = ctx->height;
     srt_render_params p{};
@@ -963,21 +1021,38 @@ int srt_estimate_row_costs(srt_context* ctx, int max_bounces, uint32_t seed, flo
     int use = 0, img = 0;
     fill_kernel_params(ctx, &p, K, lds_bytes, use, img);
     K.tile_h = srt::TILE_H;
-    const int bx = (W + srt::WG_W - 1) / srt::WG_W, by = (H + srt::WG_H - 1) / srt::WG_H, n = bx * by;
+    bx = (W + srt::WG_W - 1) / srt::WG_W, by = (H + srt::WG_H - 1) / srt::WG_H;
+    const int n = bx * by;
     uint32_t* d = nullptr;
-    SRT_HIP(ctx, hipMalloc((void**)&d, (size_t)2 * n * sizeof(uint32_t)));
+    SRT_HIP(ctx, hipMalloc((void**)&d, (size_t)(2 + (features ? 8 : 0)) * n * sizeof(uint32_t)));
+    uint32_t* d_feat = features ? d + 2 * (size_t)n : nullptr;
     const size_t image_bytes = (size_t)(K.scene_vec4 > 0 ? K.scene_vec4 : 1) * sizeof(float4);
     const size_t est_lds = (ctx->pick_in_lds[img] ? image_bytes : 0) + srt::WAVE_SCRATCH_BYTES + srt::MESH_WAVE_BYTES;
     if (ctx->pick_in_lds[img])
-        hipLaunchKernelGGL(srt::block_cost_kernel<true>, dim3((unsigned)((n + 3) / 4)), dim3(64), est_lds, ctx->stream, K, d, bx, n, d + n);
+        hipLaunchKernelGGL(srt::block_cost_kernel<true>, dim3((unsigned)((n + 3) / 4)), dim3(64), est_lds, ctx->stream, K, d, bx, n, d + n, d_feat);
     else
-        hipLaunchKernelGGL(srt::block_cost_kernel<false>, dim3((unsigned)((n + 3) / 4)), dim3(64), est_lds, ctx->stream, K, d, bx, n, d + n);
-    std::vector<uint32_t> h((size_t)n);
+        hipLaunchKernelGGL(srt::block_cost_kernel<false>, dim3((unsigned)((n + 3) / 4)), dim3(64), est_lds, ctx->stream, K, d, bx, n, d + n, d_feat);
+    balance.resize((size_t)n);
+    if (features) features->resize((size_t)8 * n);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d + n, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(balance.data(), d + n, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && features) e = hipMemcpyAsync(features->data(), d_feat, (size_t)8 * n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
-    if (e != hipSuccess) return fail(ctx, SRT_ERR_HIP, "srt_estimate_row_costs: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(ctx, SRT_ERR_HIP, "block probe: %s", hipGetErrorString(e));
+    return SRT_OK;
+}
+
+int srt_estimate_row_costs(srt_context* ctx, int max_bounces, uint32_t seed, float* row_costs) {
+    if (!ctx || !row_costs) return SRT_ERR_INVALID_ARG;
+    if (!ctx->scene_set) return fail(ctx, SRT_ERR_STATE, "srt_estimate_row_costs: srt_set_scene has not been called");
+    if (!ctx->camera.set) return fail(ctx, SRT_ERR_STATE, "srt_estimate_row_costs: srt_set_camera has not been called");
+    if (max_bounces < 0) return fail(ctx, SRT_ERR_INVALID_ARG, "srt_estimate_row_costs: max_bounces must be >= 0");
+    const int H = ctx->height;
+    std::vector<uint32_t> h;
+    int bx = 0, by = 0;
+    const int rc = run_block_probe(ctx, max_bounces, seed, h, nullptr, bx, by);
+    if (rc != SRT_OK) return rc;
     // a block covers WG_H scene rows; its cost is spread evenly over them; memory row m = scene row H - 1 - m
     for (int m = 0; m < H; ++m) row_costs[m] = 0.0f;
     for (int j = 0; j < by; ++j) {
@@ -988,6 +1063,19 @@ int srt_estimate_row_costs(srt_context* ctx, int max_bounces, uint32_t seed, flo
     }
     return SRT_OK;
 }
+
+#ifdef SRT_DEV
+// development aid (tools/band_fit.py): the probe's raw per-block sums — out[8 * (bx * by)], block (i, j) covers scene rows
+// [16 j, 16 j + 16): {probe pixels, traced, bounce rays, cluster candidates, mesh-traversal rays, misses, mesh hits, 0}
+int srt_debug_block_features(srt_context* ctx, int max_bounces, uint32_t seed, uint32_t* out, int* blocks_x, int* blocks_y) {
+    if (!ctx || !out || !blocks_x || !blocks_y) return SRT_ERR_INVALID_ARG;
+    std::vector<uint32_t> bal, feat;
+    const int rc = run_block_probe(ctx, max_bounces, seed, bal, &feat, *blocks_x, *blocks_y);
+    if (rc != SRT_OK) return rc;
+    memcpy(out, feat.data(), feat.size() * sizeof(uint32_t));
+    return SRT_OK;
+}
+#endif
 
 int srt_gather_band(srt_context* dst, srt_context* src, int row_begin, int row_end) {
     if (!dst || !src) return SRT_ERR_INVALID_ARG;

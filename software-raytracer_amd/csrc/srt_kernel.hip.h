@@ -69,6 +69,7 @@ struct KernelParams {
     // scene image layout (srt_scene_image.h)
     int32_t nu4, nc, K, nsT, nb;
     int32_t nu;  // uniform spheres that are not padding
+    float cluster_c1max;  // max over the cluster bounds of |C|_1, rounded up (distance cull of closest_hit)
     int32_t off_bounds, off_box, off_mat;
     int32_t scene_vec4;  // number of float4 in the scene image
     const float4* scene;
@@ -89,7 +90,7 @@ struct KernelParams {
     float4* sample_rows;     // [tile][sample][64 slots] sample colours
     unsigned long long* tile_masks;  // [tile] which pixels of the tile are traced (slot k = k-th set bit)
     // cost-ordered dispatch: workgroup i of the launch works on tile block wg_order[i] (NULL: i); every
-    // wave adds its run time (cycles / 256) to wg_cost[block] (NULL: not recorded) for the order of the next launch
+    // wave adds its run time (10 ns ticks of the constant clock) to wg_cost[block] (NULL: not recorded) for the order of the next launch
     const uint32_t* wg_order;
     uint32_t* wg_cost;
     float4* accumulator;
@@ -133,6 +134,10 @@ struct Prof {
 #define SRT_PROF_PARAM
 #define SRT_PROF_ARG
 #define SRT_TICK(i) do { } while (0)
+#endif
+#if defined(SRT_STATS) && SRT_STATS == 6  // make dev STATS=6: per-wave clock records for tools/timer_probe.py (the block-cost timer anomaly)
+constexpr int WAVE_LOG_MAX = 1 << 17;
+__device__ unsigned long long g_wave_log[6 * WAVE_LOG_MAX];
 #endif
 constexpr int MESH_WAVE_BYTES = (MESH_QN + MESH_QL) * 4;
 constexpr int WG_MESH_SCRATCH_BYTES = MESH_WAVE_BYTES * WG_TILES_X * WG_TILES_Y;
@@ -232,6 +237,10 @@ struct Hit {
     float t;   // distance of the recorded hit
     int prim;  // primitive id, -1 = miss (rayHit.valid == false)
     V3 n, p;   // normal, point (valid when prim >= 0)
+    // what the ray cost (read by block_cost_kernel only; dead code elsewhere): clusters whose exact spheres were tested for
+    // it, and whether it went through the mesh traversal
+    int cand;
+    bool mesh_go;
 };
 
 // ---- (distance, list index, primitive) packed so that unsigned 64-bit order == the
@@ -270,6 +279,8 @@ template <bool MESH>
 __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, V3 o, V3 d, bool active, int defer_min, bool& deferred SRT_PROF_PARAM) {
     float best = __builtin_inff();
     int bp = -1;
+    int n_cand = 0;
+    bool mesh_went = false;
     // exact sphere test of ray (ro, rd) against four spheres; updates (tb, pb) with the tie rule.
     // Part 1 (always): the cheap candidate test d2 <= r*r.  Part 2 (sqrt, compare) runs under
     // ONE wave-uniform branch per group and one more per sphere, so a group nobody can hit
@@ -333,12 +344,44 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
         }
     }
     SRT_TICK(3);
-    // ---- 2. clustered spheres
+    // ---- 2. boxes (before the clusters: in a closed room every ray meets a wall, and the clusters beyond that distance are
+    // then not even candidates, see the bound test below)
+    Hit h;
+    V3 bt1 = v3(0, 0, 0);
+    BoxRay br;
+    const int nsT = S.nsT, nb = S.nb;
+    if (nb > 0) {
+        br = box_ray_setup(d);
+        for (int j = 0; j < nb; ++j) {
+            const float4 c = S.box_c(j), hs = S.box_h(j);
+            V3 t1;
+            float dist = ibox_dist(br, v3(o.x - c.x, o.y - c.y, o.z - c.z), v3(hs.x, hs.y, hs.z), t1);
+            bool valid = active && dist != 3.402823466e+38f;  // Object.hpp:231
+            if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
+                const bool tie = valid & (dist == best) & (bp >= 0);
+                bool win = valid & (dist < best);
+                if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // rare: list indices only on an exact tie
+                    const int ob = S.order(tie ? bp : nsT + j);
+                    win = win | (tie & (S.order(nsT + j) < ob));
+                }
+                best = win ? dist : best;
+                bp = win ? nsT + j : bp;
+                // component-wise: a whole-struct select is lowered to a pointer select + copies through scratch
+                bt1 = v3(win ? t1.x : bt1.x, win ? t1.y : bt1.y, win ? t1.z : bt1.z);
+            }
+        }
+    }
+    // ---- 3. clustered spheres
     if (S.nc > 0) {
         const float dd = __builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x));
         const bool unit = fabsf(dd - 1.0f) <= 1e-6f;  // false for NaN
         if (__builtin_amdgcn_ballot_w64(active && !unit) == 0ull) {
             const float o1 = (fabsf(o.x) + fabsf(o.y)) + fabsf(o.z);
+            // A member sphere's recorded distance is t1 = |L.d| - sqrt(r^2 - d2) >= |L.d| - r (also for the mirrored sphere behind
+            // the ray and for negative distances), and |L.d| >= |(C - o).d| - |c - C|, so t1 >= |s| - R_geo; in binary32, with the
+            // rounding of L, of the dot product, of the root and of s itself: t1 >= |sd| - Rg - 2e-6 * |C - o|, and
+            // |C - o| <= |o|_1 + max |C|_1.  A cluster with |sd| - Rg beyond best + that slack cannot win, nor tie.
+            const float far = __builtin_fmaf(2e-6f, o1 + P.cluster_c1max, best);  // (+inf while nothing has been hit)
             unsigned long long mask = 0ull;
             for (int k = 0; k < S.nc; ++k) {  // phase 1: conservative cluster bounds, uniform reads
                 const float4 b = S.bound(k);
@@ -348,9 +391,10 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                 float Rinf = __builtin_fmaf(8e-6f, o1, b.w);
                 float lhs = __builtin_fmaf(-sd, sd, LL);
                 float rhs = __builtin_fmaf(4e-6f, LL, Rinf * Rinf);
-                if (lhs <= rhs) mask |= 1ull << k;
+                if ((lhs <= rhs) & (fabsf(sd) - b.w <= far)) mask |= 1ull << k;
             }
             if (!active) mask = 0ull;
+            n_cand = __builtin_popcountll(mask);
             const int K4 = S.K >> 2;
             // exclusive prefix sum of popcount(mask) over the wave: one DPP scan (six adds; seven ballot slices before)
             const int cnt = __builtin_popcountll(mask);
@@ -358,6 +402,11 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             const int prefix = (int)incl - cnt;
             const int total = __builtin_amdgcn_readlane((int)incl, 63);
             SRT_TICK(4);
+#if defined(SRT_STATS) && SRT_STATS == 4
+            SRT_STAT(2, total);
+            SRT_STAT(3, (total + 63) / 64);
+            SRT_STAT(7, __builtin_popcountll(__builtin_amdgcn_ballot_w64(active)));
+#endif
             if (total > 0 && total <= WORK_MAX) {
                 const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
                 // the lane's own best so far enters the merge slot
@@ -405,6 +454,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                 }
             }
         } else {  // some lane's direction is not unit length (degenerate lerp): brute force
+            n_cand = active ? S.nc : 0;
             for (int j = S.nu4; j < S.nsT; j += 4) {
                 const float4 s0 = S.v[j], s1 = S.v[j + 1], s2 = S.v[j + 2], s3 = S.v[j + 3];
                 test4(s0, s1, s2, s3, j, o, d, active, best, bp);
@@ -412,32 +462,6 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
         }
     }
     SRT_TICK(5);
-    // ---- 3. boxes
-    Hit h;
-    V3 bt1 = v3(0, 0, 0);
-    BoxRay br;
-    const int nsT = S.nsT, nb = S.nb;
-    if (nb > 0) {
-        br = box_ray_setup(d);
-        for (int j = 0; j < nb; ++j) {
-            const float4 c = S.box_c(j), hs = S.box_h(j);
-            V3 t1;
-            float dist = ibox_dist(br, v3(o.x - c.x, o.y - c.y, o.z - c.z), v3(hs.x, hs.y, hs.z), t1);
-            bool valid = active && dist != 3.402823466e+38f;  // Object.hpp:231
-            if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
-                const bool tie = valid & (dist == best) & (bp >= 0);
-                bool win = valid & (dist < best);
-                if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // rare: list indices only on an exact tie
-                    const int ob = S.order(tie ? bp : nsT + j);
-                    win = win | (tie & (S.order(nsT + j) < ob));
-                }
-                best = win ? dist : best;
-                bp = win ? nsT + j : bp;
-                // component-wise: a whole-struct select is lowered to a pointer select + copies through scratch
-                bt1 = v3(win ? t1.x : bt1.x, win ? t1.y : bt1.y, win ? t1.z : bt1.z);
-            }
-        }
-    }
     // ---- 4. EXTENSION: triangle meshes — traversal of the host-built 8-wide BVH (HBM/L2).
     // The triangle arithmetic is this project's definition (srt_pathtrace.h); the box filter is
     // conservative: boxes are padded per ray by 1e-5 * (|o - centre|_1 + |centre|_1 + mesh size), a
@@ -507,6 +531,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
 #ifdef SRT_DEV  // timing experiments (results are wrong): 0x100 = no mesh phases at all, 0x200 = no triangle tests
             if (P.flags & 0x100u) go = false;
 #endif
+            mesh_went = go;
             unsigned long long pend = __builtin_amdgcn_ballot_w64(go);
             const int n_go = __builtin_popcountll(pend);
             if (n_go < defer_min && n_go != __builtin_popcountll(__builtin_amdgcn_ballot_w64(active))) {
@@ -810,6 +835,8 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
     }
     h.t = best;
     h.prim = bp;
+    h.cand = n_cand;
+    h.mesh_go = mesh_went;
     h.p = v3(o.x + d.x * best, o.y + d.y * best, o.z + d.z * best);  // Object.hpp:136 / :229
     if (MESH && btri >= 0) {
         V3 n = normalized(tri_n);  // unit geometric normal, e1 x e2
@@ -952,10 +979,17 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     const int tile_h = P.tile_h;
     // which block of tiles: the hardware starts workgroups in linear order, wg_order maps that order to
     // blocks sorted by decreasing cost so that the expensive ones do not end up in the tail
-#if defined(SRT_STATS) && SRT_STATS == 5
+#if defined(SRT_STATS) && SRT_STATS == 6
+    const long long t_start = (long long)__builtin_readcyclecounter();
+    const unsigned long long r_start = __builtin_amdgcn_s_memrealtime();
+    const unsigned hw_start = __builtin_amdgcn_s_getreg(0xF804), xcc_start = __builtin_amdgcn_s_getreg(0xF814);  // HW_ID, XCC_ID
+#elif defined(SRT_STATS) && SRT_STATS == 5
     const long long t_start = (long long)__builtin_readcyclecounter();
 #else
-    const long long t_start = P.wg_cost ? (long long)__builtin_readcyclecounter() : 0;
+    // block costs are timed with s_memrealtime, the constant 100 MHz clock all XCDs share — NOT with s_memtime
+    // (__builtin_readcyclecounter): that one is a per-XCD shader-clock counter (tools/timer_probe.py: the eight XCDs' values lie
+    // 4e10 .. 1.8e11 ticks apart), and a difference of two of its readings was seen to come out negative on some boxes
+    const long long t_start = P.wg_cost ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 #endif
     uint32_t block_id = blockIdx.y * gridDim.x + blockIdx.x;
     if (P.wg_order) block_id = P.wg_order[block_id];
@@ -1217,6 +1251,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         uint32_t own_next = own_done;
         int rot = 0;  // wave-uniform rotation of the slot priority
         const int fold_pace = (63 + n_hit) / n_hit;
+        const int max_pass = MULTI ? 2 : (n_hit >= 32 ? 2 : (n_hit >= 16 ? 4 : 8));
 
         while (true) {
             SRT_TICK(7);
@@ -1253,6 +1288,10 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 }
                 const unsigned long long readym = __builtin_amdgcn_ballot_w64(ready);
                 if (readym == 0ull) break;
+#if defined(SRT_STATS) && SRT_STATS == 4
+                SRT_STAT(4, 1);
+                SRT_STAT(5, __builtin_popcountll(readym));
+#endif
                 // long paths (Scene_indirect: 8 rays per sample) finish a few samples per step: a fold for fewer than a fifth of
                 // the slots waits for the next step's, unless a slot is out of ring capacity or the hand-out has ended
                 if (it == 0 && !drain && __builtin_popcountll(readym) * 5 < n_hit &&
@@ -1276,7 +1315,9 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             // free lanes than such slots, the lanes are dealt round-robin to the slots and a slot hands out
             // as many consecutive samples as it is dealt lanes, up to its capacity — so a small tile
             // (P.tile_h) still keeps all 64 lanes busy
-            for (int pass = 0; pass < 2; ++pass) {
+            // (two passes keep a well-filled tile busy; a tile with few traced pixels needs more — every pass starts at most one
+            // sample per slot — or most of its lanes never work: up to 8 passes below 16 slots, 4 below 32)
+            for (int pass = 0; pass < max_pass; ++pass) {
                 const unsigned long long freem = __builtin_amdgcn_ballot_w64(!busy);
                 const uint32_t lim = count < own_done + (uint32_t)depth ? count : own_done + (uint32_t)depth;
                 const int avail = own_next < lim ? (int)(lim - own_next) : 0;
@@ -1339,6 +1380,11 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             }
 
             SRT_TICK(1);
+#if defined(SRT_STATS) && SRT_STATS == 4  // make dev STATS=4: lane occupancy of the pool (tests/pool_stats.py)
+            SRT_STAT(0, 1);
+            SRT_STAT(1, __builtin_popcountll(__builtin_amdgcn_ballot_w64(busy)));
+            SRT_STAT(6, n_hit);
+#endif
             // ---- one bounce for every busy lane
             V3 o = v3(0, 0, 0);
             const float ofs = .00001f;
@@ -1416,18 +1462,196 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
 #if defined(SRT_STATS) && SRT_STATS == 5
     SRT_STAT(7, (long long)__builtin_readcyclecounter() - t_start);  // the wave's whole life
 #endif
+#if defined(SRT_STATS) && SRT_STATS == 6
+    {
+        const long long t_end = (long long)__builtin_readcyclecounter();
+        const unsigned long long r_end = __builtin_amdgcn_s_memrealtime();
+        const unsigned hw_end = __builtin_amdgcn_s_getreg(0xF804), xcc_end = __builtin_amdgcn_s_getreg(0xF814);
+        const size_t w = ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (WG_TILES_X * WG_TILES_Y) + wave;
+        if (lane == 0 && w < (size_t)WAVE_LOG_MAX) {
+            unsigned long long* e = g_wave_log + 6 * w;
+            e[0] = (unsigned long long)t_start, e[1] = (unsigned long long)t_end, e[2] = r_start, e[3] = r_end;
+            e[4] = (unsigned long long)hw_start | ((unsigned long long)xcc_start << 32), e[5] = (unsigned long long)hw_end | ((unsigned long long)xcc_end << 32);
+        }
+    }
+#endif
     if ((P.flags & 2u) || P.wg_cost) {  // SRT_RENDER_COUNT_RAYS / cost feedback for the dispatch order
         unsigned long long tot = rays;
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
         if (lane == 0 && tot) {
             if (P.flags & 2u) atomicAdd(P.ray_counter, tot);
             if (P.wg_cost) {
-                // (a wave whose two counter reads do not belong together — seen on some boxes as a difference of minus the
-                // launch's length, presumably a wave that was saved and restored in between — records nothing)
-                const long long dt = (long long)__builtin_readcyclecounter() - t_start;
-                if (dt > 0 && dt < (1ll << 40)) atomicAdd(&P.wg_cost[block_id], (uint32_t)(dt >> 8));
+                // the wave's run time in 10 ns ticks; should the two readings ever not belong together, the wave's ray count
+                // stands in (about 16 ticks per ray at the usual rates) instead of a zero that would push the block to the tail
+                const long long dt = (long long)__builtin_amdgcn_s_memrealtime() - t_start;
+                atomicAdd(&P.wg_cost[block_id], (dt > 0 && dt < (1ll << 28)) ? (uint32_t)dt : (uint32_t)(tot < (1ull << 24) ? tot * 16ull : (1ull << 28)));
             }
         }
+    }
+}
+
+// ---- one-sample launches: the reference's own frame loop adds ONE sample per frame (Raytracer.cpp:572-595) ---------------
+// With one sample per pixel there is nothing to keep in order — the pixel's one colour is folded into its running mean by
+// whichever lane finishes the path — and nothing to reuse (the primary hit serves one sample).  So this kernel streams:
+// resident waves pull chunks of 256 pixels (a 32 x 8 strip) from a counter in device memory; a free lane takes the next pixel of
+// its wave's chunk and traces the path from the PRIMARY ray on; every step all busy lanes — primary and bounce rays alike — go
+// through one cooperative closest_hit; a lane whose path ends accumulates, tone-maps and stores its pixel and is free again.
+// The wave stays full until the launch runs out of pixels: one thin tail per launch, where pathtrace_kernel's pool (64 pixels,
+// one sample each) thins out per wave — a wave kept its tile until the longest of 64 paths ended.  Same arithmetic, same
+// random stream (keyed by pixel and sample), same bits.
+constexpr int ONE_CHUNK_W = 32, ONE_CHUNK_H = 8, ONE_CHUNK = ONE_CHUNK_W * ONE_CHUNK_H;
+template <int MIN_WAVES, bool MESH, bool SCENE_LDS>
+__global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_one_kernel(const KernelParams P, unsigned* work_counter, unsigned* next_launch_counter) {
+    extern __shared__ float4 lds_scene[];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *next_launch_counter = 0u;  // (nothing reads it before the next launch of this context)
+#if defined(SRT_STATS) && SRT_STATS == 3
+    Prof prof;
+    prof.last = (long long)__builtin_readcyclecounter();
+    for (int i = 0; i < 8; ++i) prof.acc[i] = 0;
+#endif
+    if constexpr (SCENE_LDS) {
+        for (int i = threadIdx.x; i < P.scene_vec4; i += WG_THREADS) lds_scene[i] = P.scene[i];
+        __syncthreads();
+    }
+    const Lds S = make_lds<SCENE_LDS>(P, lds_scene, WG_TILES_X * WG_TILES_Y, threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int W = P.width;
+    const int strips_x = (W + ONE_CHUNK_W - 1) / ONE_CHUNK_W, strips_y = (P.rows + ONE_CHUNK_H - 1) / ONE_CHUNK_H;
+    const unsigned n_chunks = (unsigned)(strips_x * strips_y);
+    const int B = P.max_bounces;
+    const V3 cam = v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
+    const float ofs = .00001f;
+
+    // the wave's chunk (wave-uniform) and how far it has been handed out
+    int cx0 = 0, cy0 = 0, c_next = ONE_CHUNK;
+    bool more = true;  // the launch may still have chunks
+    // this lane's path
+    bool busy = false, primary = false, parked = false;
+    uint32_t pixel = 0;
+    RGB L{0, 0, 0}, T{0, 0, 0};
+    V3 sray = v3(0, 0, 1), hn = v3(0, 0, 0), hp = v3(0, 0, 0);
+    int hprim = 0, bounce = 0;
+    float spec = 0.0f;
+    uint32_t rng = 0;
+    unsigned rays = 0;
+
+    while (true) {
+        SRT_TICK(7);
+        // ---- hand out pixels to the free lanes: the i-th free lane takes the chunk's (c_next + i)-th pixel
+        for (int pass = 0; pass < 2; ++pass) {
+            const unsigned long long freem = __builtin_amdgcn_ballot_w64(!busy);
+            if (freem == 0ull) break;
+            if (c_next >= ONE_CHUNK) {
+                if (!more) break;
+                unsigned c = 0;
+                if (lane == 0) c = atomicAdd(work_counter, 1u);
+                c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
+                if (c >= n_chunks) {
+                    more = false;
+                    break;
+                }
+                const int sy = (int)(c / (unsigned)strips_x);
+                cx0 = ((int)c - sy * strips_x) * ONE_CHUNK_W, cy0 = sy * ONE_CHUNK_H;
+                c_next = 0;
+            }
+            const int nfree = __builtin_popcountll(freem);
+            const int frank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(freem >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)freem, 0u));
+            const int l = c_next + frank;  // 8 x 8 tiles side by side: pixel l of the chunk is pixel l & 63 of tile l >> 6
+            c_next += nfree;
+            if (!busy && l < ONE_CHUNK) {
+                const int x = cx0 + (l >> 6) * TILE_W + (l & (TILE_W - 1)), ty = cy0 + ((l >> 3) & (TILE_H - 1));
+                if (x < W && ty < P.rows) {
+                    const int y = P.y0 + ty;
+                    pixel = (uint32_t)(x + y * W);
+                    // GetRayDirection (Raytracer.cpp:106-122)
+                    float nX = ((float)x / (float)W) * 2 - 1;
+                    float nY = ((float)y / (float)P.height) * 2 - 1;
+                    V3 u = v3(P.right_rd[0] * nX, P.right_rd[1] * nX, P.right_rd[2] * nX);
+                    V3 vv = v3(P.up_ld[0] * nY, P.up_ld[1] * nY, P.up_ld[2] * nY);
+                    sray = normalized(v3((u.x + vv.x) + P.fwd_clip[0], (u.y + vv.y) + P.fwd_clip[1], (u.z + vv.z) + P.fwd_clip[2]));
+                    busy = true, primary = true, parked = false;
+                }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(busy) == 0ull) {
+            if (!more && c_next >= ONE_CHUNK) break;  // no pixel left anywhere for this wave
+            continue;
+        }
+        SRT_TICK(1);
+        // ---- the ray of every busy lane: the primary ray, or one bounce (Raytracer.cpp:169-177)
+        V3 o = v3(0, 0, 0);
+        if (busy && primary) {
+            o = cam;
+        } else if (MESH && busy && parked) {  // the ray made earlier, offered to the mesh phase again
+            o = v3(hp.x + hn.x * ofs, hp.y + hn.y * ofs, hp.z + hn.z * ofs);
+        } else if (busy) {
+            if (bounce != 0) {  // :169-171
+                T = RGB{clamp0(T.r * 0.8f), clamp0(T.g * 0.8f), clamp0(T.b * 0.8f)};
+            }
+            float k2 = 2 * dot3(sray, hn);  // :172, Common.hpp:163-165
+            V3 refl = v3(sray.x - hn.x * k2, sray.y - hn.y * k2, sray.z - hn.z * k2);
+            uint32_t r0 = srt_mix32(rng) >> 17;  // :90-105: exactly three draws, x then y then z
+            uint32_t r1 = srt_mix32(rng + 0x9E3779B9U) >> 17;
+            uint32_t r2 = srt_mix32(rng + 2u * 0x9E3779B9U) >> 17;
+            rng += 3u * 0x9E3779B9U;
+            V3 sr = v3((rand_unit(r0) - 0.5f) * 2, (rand_unit(r1) - 0.5f) * 2, (rand_unit(r2) - 0.5f) * 2);
+            sr = normalized(sr);
+            if (dot3(sr, hn) < 0) sr = v3(sr.x * -1, sr.y * -1, sr.z * -1);
+            float tt = S.mat(hprim, 0).x * spec;  // :175
+            V3 l = v3(sr.x * (1 - tt) + refl.x * tt, sr.y * (1 - tt) + refl.y * tt, sr.z * (1 - tt) + refl.z * tt);
+            sray = normalized(l);  // :176
+            o = v3(hp.x + hn.x * ofs, hp.y + hn.y * ofs, hp.z + hn.z * ofs);  // :177
+        }
+        const Hit h = closest_hit<MESH>(S, P, o, sray, busy, P.mesh_defer, parked SRT_PROF_ARG);
+        if (busy && !(MESH && parked)) {
+            ++rays;
+            bool end_path;
+            if (h.prim < 0) {  // :143-145 (primary) / :178-181
+                RGB e = environment(P, sray);
+                L = primary ? e : RGB{clamp0(L.r + clamp0(e.r * T.r)), clamp0(L.g + clamp0(e.g * T.g)), clamp0(L.b + clamp0(e.b * T.b))};
+                end_path = true;
+            } else {
+                float4 m0 = S.mat(h.prim, 0), m1 = S.mat(h.prim, 1), m2 = S.mat(h.prim, 2);
+                if (primary) rng = srt_rng_key(P.seed, pixel, P.first_sample);
+                uint32_t r = srt_mix32(rng) >> 17;
+                rng += 0x9E3779B9U;
+                spec = (m0.y >= rand_unit(r)) ? 1.0f : 0.0f;  // :165 / :182
+                RGB Em{clamp0(m1.y), clamp0(m1.z), clamp0(m1.w)}, Bc{clamp0(m0.z), clamp0(m0.w), clamp0(m1.x)};
+                if (primary) {  // :162-163
+                    L = Em;
+                    T = Bc;
+                    bounce = 0;
+                    end_path = B <= 0;
+                } else {
+                    L = RGB{clamp0(L.r + clamp0(Em.r * T.r)), clamp0(L.g + clamp0(Em.g * T.g)), clamp0(L.b + clamp0(Em.b * T.b))};  // :183
+                    RGB Sc{clamp0(m2.x), clamp0(m2.y), clamp0(m2.z)};
+                    RGB f = color_lerp(Bc, Sc, spec);  // :184
+                    T = RGB{clamp0(T.r * f.r), clamp0(T.g * f.g), clamp0(T.b * f.b)};
+                    ++bounce;
+                    end_path = bounce >= B;
+                }
+                hn = h.n;
+                hp = h.p;
+                hprim = h.prim;
+            }
+            primary = false;
+            if (end_path) {  // SetScreenPixel (:63-76) for this pixel's one sample
+                float4 acc = (P.flags & 1u) ? make_float4(0, 0, 0, 0) : P.accumulator[pixel];
+                accumulate_sample(P, acc, L, 0);
+                store_pixel(P, pixel, acc);
+                busy = false;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#if defined(SRT_STATS) && SRT_STATS == 3
+    SRT_TICK(7);
+    for (int i = 0; i < 8; ++i) SRT_STAT(i, prof.acc[i] > 0 ? prof.acc[i] : 0);
+#endif
+    if (P.flags & 2u) {  // SRT_RENDER_COUNT_RAYS
+        unsigned long long tot = rays;
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
+        if (lane == 0 && tot) atomicAdd(P.ray_counter, tot);
     }
 }
 
@@ -1503,8 +1727,13 @@ __global__ void __launch_bounds__(64) pick_kernel(const KernelParams P, int px, 
 // (measured: ordering by primary hits left the first launch of config 4 13 % and of Scene3 10 % behind the
 // learned order).  Any order gives the same image.
 constexpr int ORDER_BUCKETS = 16, ORDER_SORT_THREADS = 512;
+// Balance cost (srt_estimate_row_costs): TIME a block's pixels will take per sample, in 1/64 of the time of one analytic bounce
+// ray that meets no cluster.  Weights fitted by least squares on measured band times of configs 3 and 5 (tools/band_fit.py,
+// DESIGN.md §5): a sample of a pixel that traces nothing (the running mean is still evaluated sample by sample), a bounce ray,
+// every cluster whose spheres are tested exactly for it, a ray that goes through the mesh traversal, one that ends on a mesh.
+constexpr unsigned BAL_W_PIXEL = 7u, BAL_W_RAY = 64u, BAL_W_CAND = 0u, BAL_W_MESH_GO = 0u, BAL_W_MESH_HIT = 320u;
 template <bool SCENE_LDS>
-__global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, uint32_t* cost, int blocks_x, int n_blocks, uint32_t* balance_cost) {
+__global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, uint32_t* cost, int blocks_x, int n_blocks, uint32_t* balance_cost, uint32_t* features) {
     extern __shared__ float4 lds_scene[];
     if constexpr (SCENE_LDS) {
         for (int i = threadIdx.x; i < P.scene_vec4; i += 64) lds_scene[i] = P.scene[i];
@@ -1533,7 +1762,8 @@ __global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, ui
     // of one bounce ray — a sample of a pixel that traces nothing costs about 0.11 of that (the running mean is still
     // evaluated sample by sample), the primary ray is traced once per pixel whatever the sample count (free), a bounce ray
     // that ends on a mesh about six times an analytic one (fitted to measured bands of configs 3 and 5)
-    unsigned cb = in_range ? 7u : 0u;
+    unsigned cb = in_range ? BAL_W_PIXEL : 0u;
+    unsigned f_traced = 0u, f_rays = 0u, f_cand = 0u, f_go = 0u, f_miss = 0u, f_meshhit = 0u;  // (fitting aid, see `features`)
     bool alive = in_range && h.prim >= 0 && P.max_bounces > 0 && !(P.flags & 4u);
     uint32_t rng = srt_rng_key(P.seed, (uint32_t)(x + y * P.width), P.first_sample);
     float spec = 0.0f;
@@ -1541,6 +1771,7 @@ __global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, ui
         spec = (S.mat(h.prim, 0).y >= rand_unit(srt_mix32(rng) >> 17)) ? 1.0f : 0.0f;
         rng += 0x9E3779B9U;
         c += h.prim >= first_mesh_prim ? (SRT_MESH_ORDER_W - 1u) : 0u;
+        f_traced = 1u;
     }
     for (int bounce = 0; bounce < P.max_bounces && __builtin_amdgcn_ballot_w64(alive) != 0ull; ++bounce) {
         V3 o = v3(0, 0, 0);
@@ -1559,7 +1790,8 @@ __global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, ui
         const Hit g = closest_hit<true>(S, P, o, sray, alive, 1, deferred SRT_PROF_ARG);
         if (alive) {
             c += g.prim >= first_mesh_prim ? SRT_MESH_ORDER_W : 1u;
-            cb += g.prim >= first_mesh_prim ? 384u : 64u;
+            cb += BAL_W_RAY + BAL_W_CAND * (unsigned)g.cand + (g.mesh_go ? BAL_W_MESH_GO : 0u) + (g.prim >= first_mesh_prim ? BAL_W_MESH_HIT : 0u);
+            f_rays += 1u, f_cand += (unsigned)g.cand, f_go += g.mesh_go ? 1u : 0u, f_miss += g.prim < 0 ? 1u : 0u, f_meshhit += g.prim >= first_mesh_prim ? 1u : 0u;
             if (g.prim < 0) {
                 alive = false;
             } else {
@@ -1573,6 +1805,13 @@ __global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, ui
     if (k == 0 && block < n_blocks) {
         cost[block] = c;
         if (balance_cost) balance_cost[block] = cb;
+    }
+    if (features) {  // development aid (tools/band_fit.py): the raw sums the balance weights are fitted on, 8 words per block
+        unsigned f[8] = {in_range ? 1u : 0u, f_traced, f_rays, f_cand, f_go, f_miss, f_meshhit, 0u};
+        for (int i = 0; i < 7; ++i) {
+            for (int off = 8; off > 0; off >>= 1) f[i] += __shfl_down(f[i], off, 16);
+            if (k == 0 && block < n_blocks) features[(size_t)block * 8 + i] = f[i];
+        }
     }
 }
 

@@ -64,6 +64,7 @@ struct SceneLayout {
     int off_bounds = 0, off_box = 0, off_mat = 0;
     int total_vec4 = 0;
     int n_spheres = 0;  // real spheres (for statistics)
+    float cluster_c1max = 0.0f;  // max over the cluster bounds of |Cx| + |Cy| + |Cz|, rounded up
 };
 
 inline uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) {  // 10 bits per axis
@@ -256,6 +257,10 @@ inline SceneLayout build_scene_image(const srt_object* objects, size_t count, bo
         float Rgf = (float)Rg;
         if ((double)Rgf < Rg) Rgf = nextafterf(Rgf, INFINITY);
         img[L.off_bounds + c] = make_float4(Cf[0], Cf[1], Cf[2], Rgf);
+        const double c1 = (fabs((double)Cf[0]) + fabs((double)Cf[1]) + fabs((double)Cf[2])) * (1.0 + 1e-6);
+        float c1f = (float)c1;
+        if ((double)c1f < c1) c1f = nextafterf(c1f, INFINITY);
+        L.cluster_c1max = std::max(L.cluster_c1max, c1f);
     }
     for (size_t j = 0; j < boxes.size(); ++j) {
         const srt_object& o = objects[boxes[j]];

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Interleaved timing of several BUILDS of the library (different source versions) on several workloads, in ONE process on
+one box: the only comparison that means anything on this pool (boxes differ by ~2 %, clocks drift within a run).
+usage: python tests/ab_libs.py --libs base=path/a.so,new=path/b.so [--work c2,indirect,c4,c3r7,c3r4,1spp,1spp_ind] [--rounds 7]
+Every library renders every workload once per round, in turn; prints the median / min kernel ms per (workload, library),
+the ratio to the first library, and checks that all libraries produce the same framebuffer."""
+import argparse
+import hashlib
+import importlib
+import json
+import os
+import statistics
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+WORK = {  # name: scene, mesh, width, height, spp, bounces, memory rows (None = all)
+    "c2": ("Scene1", 0, 1920, 1080, 32, 8, None),
+    "indirect": ("Scene_indirect", 0, 1920, 1080, 32, 8, None),
+    "scene3": ("Scene3", 0, 1920, 1080, 32, 8, None),
+    "refl": ("Scene1_reflection", 0, 1920, 1080, 32, 8, None),
+    "c4": ("Scene1", 224, 1920, 1080, 64, 8, None),
+    "c3r4": ("Scene1", 0, 1920, 1080, 512, 8, (540, 675)),
+    "c3r7": ("Scene1", 0, 1920, 1080, 512, 8, (945, 1080)),
+    "c5r4": ("Scene1", 224, 3840, 2160, 1024, 16, (1080, 1350)),
+    "1spp": ("Scene1", 0, 1920, 1080, 1, 8, None),
+    "1spp_ind": ("Scene_indirect", 0, 1920, 1080, 1, 8, None),
+    "1spp_c4": ("Scene1", 224, 1920, 1080, 1, 8, None),
+}
+ap = argparse.ArgumentParser()
+ap.add_argument("--libs", required=True)
+ap.add_argument("--work", default="c2,indirect")
+ap.add_argument("--rounds", type=int, default=7)
+ap.add_argument("--warm", type=int, default=3)
+a = ap.parse_args()
+srt = importlib.import_module("software-raytracer_amd")
+libs = []
+for item in a.libs.split(","):
+    name, path = item.split("=")
+    libs.append((name, srt.capi.open_library(os.path.join(ROOT, path))))
+for wname in a.work.split(","):
+    scene, mesh, W, H, spp, bounces, rows = WORK[wname]
+    path = os.path.join(ROOT, "software-raytracer_amd", "scenes", scene + ".json")
+    if mesh:
+        sj = json.load(open(path))
+        sj["SceneObjects"][64]["Renderer"] = {"Type": "Mesh", "Primitive": "UVSphere", "Radius": 1.0, "Stacks": mesh, "Slices": mesh}
+        tmp = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
+        json.dump(sj, tmp)
+        tmp.close()
+        path = tmp.name
+    sc = srt.host.Scene(path)
+    if mesh:
+        os.unlink(path)
+    objs, n = sc.objects_copy()
+    meshes, nm = sc.meshes()
+    pts = []
+    for name, L in libs:
+        pt = srt.PathTracer(W, H, lib=L)
+        pt.set_meshes(meshes, nm)
+        pt.set_scene(objs, n)
+        pt.set_camera(srt.default_camera())
+        pts.append(pt)
+    times = [[] for _ in libs]
+    hashes = [None] * len(libs)
+    for r in range(a.warm + a.rounds):
+        for i, pt in enumerate(pts):
+            pt.render(spp=spp, bounces=bounces, seed=0, rows=rows)
+            ms = pt.stats().kernel_ms
+            if r >= a.warm:
+                times[i].append(ms)
+            elif r == 0:
+                hashes[i] = hashlib.sha256(pt.framebuffer(rows).tobytes()).hexdigest()[:12]
+    base = statistics.median(times[0])
+    px = W * ((rows[1] - rows[0]) if rows else H)
+    for i, (name, _) in enumerate(libs):
+        med = statistics.median(times[i])
+        print("%-9s %-10s median %8.3f ms  min %8.3f  x%.3f vs %s  %.3e samples/s  hash %s" %
+              (wname, name, med, min(times[i]), med / base, libs[0][0], px * spp / (med * 1e-3), hashes[i]), flush=True)
+    for pt in pts:
+        pt.close()
+    if len(set(hashes)) != 1:
+        print("!!! %s: the libraries DISAGREE" % wname, flush=True)
+        sys.exit(1)

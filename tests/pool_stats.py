@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Development aid: lane occupancy of pathtrace_kernel's path pool (development library, STATS=4 counters).
+usage: python tests/pool_stats.py [--scene Scene1] [--spp 32] [--mesh 0] [--rows a,b] [--width 1920 --height 1080]"""
+import argparse, ctypes as C, importlib, json, os, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument("--scene", default="Scene1")
+ap.add_argument("--spp", type=int, default=32)
+ap.add_argument("--bounces", type=int, default=8)
+ap.add_argument("--mesh", type=int, default=0)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--rows", default="")
+a = ap.parse_args()
+srt = importlib.import_module("software-raytracer_amd")
+srt.capi.use_dev_library(stats=4)
+L = srt.load_library()
+path = os.path.join(ROOT, "software-raytracer_amd", "scenes", a.scene + ".json")
+if a.mesh:
+    sj = json.load(open(path))
+    sj["SceneObjects"][64]["Renderer"] = {"Type": "Mesh", "Primitive": "UVSphere", "Radius": 1.0, "Stacks": a.mesh, "Slices": a.mesh}
+    tmp = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False); json.dump(sj, tmp); tmp.close(); path = tmp.name
+sc = srt.host.Scene(path)
+objs, n = sc.objects_copy(); meshes, nm = sc.meshes()
+pt = srt.PathTracer(a.width, a.height)
+pt.set_meshes(meshes, nm); pt.set_scene(objs, n); pt.set_camera(srt.default_camera())
+rows = tuple(int(v) for v in a.rows.split(",")) if a.rows else None
+out = (C.c_ulonglong * 8)()
+for _ in range(3):
+    pt.render(spp=a.spp, bounces=a.bounces, seed=0, count_rays=True, rows=rows); st = pt.stats(); L.srt_debug_read_stats(out)
+o = list(out)
+steps = max(o[0], 1)
+print("%s%s spp %d rows %s: kernel %.3f ms (with counters), %d sample chunks, rays %d" % (a.scene, "+mesh" if a.mesh else "", a.spp, a.rows or "all", st.kernel_ms, st.sample_chunks, st.rays))
+print("  pool steps %d, busy lanes per step %.1f of 64, traced pixels per tile (step-weighted) %.1f" % (o[0], o[1] / steps, o[6] / steps))
+print("  closest_hit calls with clusters %d: active lanes %.1f, cluster items per call %.1f (%.2f per active lane), exact rounds per call %.2f" %
+      (o[3] and (o[3] * 0 + 1) and 0 or 0, 0, 0, 0, 0) if False else "  cluster items per step %.1f (%.2f per active lane), exact rounds per step %.2f" % (o[2] / steps, o[2] / max(o[7], 1), o[3] / steps))
+print("  fold iterations per step %.2f, slots folded per iteration %.1f" % (o[4] / steps, o[5] / max(o[4], 1)))

@@ -52,7 +52,9 @@ def main():
     only = None
     if len(sys.argv) > 3 and sys.argv[2] == "--only":
         only = set(sys.argv[3].split(","))
-    out = os.path.join(ROOT, "profiles", rnd)
+    # everything is written twice: into profiles/ (bench.py reads counters.json / mesh_counts.json from there) and into
+    # gpurun_out/profiles/ — the only directory a gpurun call brings back; `cp -r gpurun_out/profiles/. profiles/` afterwards
+    out = os.path.join(ROOT, "gpurun_out", "profiles", rnd)
     scratch = os.path.join(ROOT, "gpurun_out", "profile_" + rnd)
     os.makedirs(out, exist_ok=True)
     os.makedirs(scratch, exist_ok=True)
@@ -111,6 +113,7 @@ def main():
                 entry["hbm_bytes_per_launch"] = k["hbm_bytes"]
             counters[key] = entry
             json.dump(counters, open(cpath, "w"), indent=1, sort_keys=True)
+            json.dump(counters, open(os.path.join(ROOT, "gpurun_out", "profiles", "counters.json"), "w"), indent=1, sort_keys=True)
             open(os.path.join(out, "pmc_%s.json" % name), "w").write(json.dumps(doc, indent=1, sort_keys=True))
         else:
             print(name, "pmc failed:", r.stdout[-300:], r.stderr[-300:])
@@ -130,6 +133,7 @@ def main():
                                     "mesh_rays_per_sample": ms["go lanes"] / samples, "mesh_phases": ms["mesh phases (waves)"],
                                     "source": "tests/mesh_stats.py (development library, STATS=1 counters), %dx%d rows %d-%d, 8 spp, %d bounces" % (w, h, rb, re_, b)}
                 json.dump(mesh_counts, open(mpath, "w"), indent=1, sort_keys=True)
+                json.dump(mesh_counts, open(os.path.join(ROOT, "gpurun_out", "profiles", "mesh_counts.json"), "w"), indent=1, sort_keys=True)
             else:
                 print(name, "mesh_stats failed:", r.stdout[-300:], r.stderr[-300:])
         # 5. the bench line that is committed (reads the counters written above; with the CPU baseline where it is cheap)
