@@ -7,9 +7,11 @@ streaming fold; one framebuffer + accumulator store per pixel), plus — for N >
 
 Workloads (BASELINE.json `configs`, 1-based like SURVEY §8):
   N = 1 (default)      config 2: Scenes/Scene1.json, 1920x1080, 32 spp, 8 bounces, camera at origin, FOV 55.
-  N > 1 (the driver)   config 3's frame and scene, row-striped in EQUAL memory-row bands, 64*N spp
-                       (per-GPU path-samples fixed for N >= 2 -> "weak"; N = 8 is exactly config 3:
-                       512 spp), joined by ONE dist.gather to rank 0 over RCCL.
+  N > 1 (the driver)   config 3's frame and scene, row-striped in contiguous memory-row bands of equal ESTIMATED
+                       cost (the library's device-side probe, srt_estimate_row_costs: deterministic, every rank
+                       computes the same split, no collective, no calibration launch; --balance equal = bands of
+                       equal height), 64*N spp (per-GPU path-samples fixed for N >= 2 -> "weak"; N = 8 is
+                       exactly config 3: 512 spp), joined by ONE dist.gather to rank 0 over RCCL.
   --config C           any of configs 2..5 in its stated form (4 and 5 use the 99,904-triangle ball).
   --rank k/N           with --config: render rank k's share of an N-rank run (equal stripe, the
                        config's full spp) on ONE GPU — how configs 3 and 5 are exercised without an
@@ -125,11 +127,12 @@ def main():
     ap.add_argument("--mesh", type=int, default=None, metavar="N", help="EXTENSION: replace Scene1's big ball by an N x N tessellation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the bounded CPU sample (16 spp at 1080p = about 20 s of CPU work)")
-    ap.add_argument("--balance", default="equal", choices=["equal", "probe", "cost"],
-                    help="row-stripe split for N > 1 (and for --rank): equal bands + one dist.gather (north_star); 'probe': bands of "
-                         "equal estimated cost from the library's device-side probe (srt_estimate_row_costs, ~0.1 ms, deterministic: "
-                         "no collective, no extra launch) + one padded dist.gather; 'cost': a 1-spp ray-count probe per 8 rows and one "
-                         "calibration launch with an all_gather (their cost is reported in the JSON; never inside the timed region)")
+    ap.add_argument("--balance", default="probe", choices=["equal", "probe", "cost"],
+                    help="row-stripe split for N > 1 (and for --rank): 'probe' (default): contiguous bands of equal estimated cost from the "
+                         "library's device-side probe (srt_estimate_row_costs, ~0.1 ms, deterministic: no collective, no extra launch) + one "
+                         "dist.gather of bands padded to the tallest; 'equal': bands of equal height + one in-place dist.gather (north_star's "
+                         "literal form; on sky-over-floor scenes the slowest of 8 takes 2.2x the mean); 'cost': a 1-spp ray-count probe per "
+                         "8 rows and one calibration launch with an all_gather (their cost is reported in the JSON; never inside the timed region)")
     ap.add_argument("--gather", default="padded", choices=["padded", "p2p"],
                     help="cost-balanced (unequal) bands only: one dist.gather of bands padded to the tallest, or one grouped isend/irecv")
     args = ap.parse_args()
@@ -221,9 +224,9 @@ def main():
     if n_parts > 1 and args.balance == "probe":
         t_cal = time.perf_counter()
         row_cost = pt.estimate_row_costs(bounces, SEED)
-        bands = stripes.partition_rows(H, n_parts, row_cost, align=8)
-        calibration = {"calibration_launches": 1, "calibration_ms": (time.perf_counter() - t_cal) * 1e3,
-                       "calibration": "srt_estimate_row_costs: one device-side probe of 1/16 of the pixels at one sample, same numbers on every rank"}
+        bands = stripes.partition_rows(H, n_parts, row_cost, align=16)  # whole blocks of tiles
+        calibration = {"calibration_launches": 0, "probe_launches": 1, "calibration_ms": (time.perf_counter() - t_cal) * 1e3,
+                       "calibration": "none: srt_estimate_row_costs is one device-side probe of 1/16 of the pixels at one sample (no launch of the workload), same numbers on every rank"}
         rb, re = bands[share[0] if share else rank]
     elif share:
         bands = stripes.partition_rows(H, share[1])

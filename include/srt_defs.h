@@ -88,46 +88,50 @@ typedef union srt_f32bits {
 /* ln(m) for m in [1,2) comes from a 32-entry table: i = the top five mantissa bits, c_i = 1 + (i + 0.5)/32,
  * pair (invc_i, lnc_i) = (RN(1/c_i), RN(-ln(invc_i))), so that ln(m) = lnc_i + ln(1 + s) with s = m*invc_i - 1
  * (one exact-enough FMA, |s| < 1/64) — no division, a degree-7 series.  Generated with 60-digit arithmetic by
- * tools/gen_pow_table.py.  On the device the table lives in constant memory. */
+ * tools/gen_pow_table.py. */
+#define SRT_POW_TABLE_INIT { \
+    0x1.f81f81f81f820p-1, 0x1.fc0a8b0fc03c4p-7,  /* c = 1 + 0.5/32 */ \
+    0x1.e9131abf0b767p-1, 0x1.77458f632dcffp-5,  /* c = 1 + 1.5/32 */ \
+    0x1.dae6076b981dbp-1, 0x1.341d7961bd1d0p-4,  /* c = 1 + 2.5/32 */ \
+    0x1.cd85689039b0bp-1, 0x1.a926d3a4ad562p-4,  /* c = 1 + 3.5/32 */ \
+    0x1.c0e070381c0e0p-1, 0x1.0d77e7cd08e5bp-3,  /* c = 1 + 4.5/32 */ \
+    0x1.b4e81b4e81b4fp-1, 0x1.44d2b6ccb7d1cp-3,  /* c = 1 + 5.5/32 */ \
+    0x1.a98ef606a63bep-1, 0x1.7ab890210d907p-3,  /* c = 1 + 6.5/32 */ \
+    0x1.9ec8e951033d9p-1, 0x1.af3c94e80bff3p-3,  /* c = 1 + 7.5/32 */ \
+    0x1.948b0fcd6e9e0p-1, 0x1.e27076e2af2e8p-3,  /* c = 1 + 8.5/32 */ \
+    0x1.8acb90f6bf3aap-1, 0x1.0a324e27390e2p-2,  /* c = 1 + 9.5/32 */ \
+    0x1.8181818181818p-1, 0x1.22941fbcf7966p-2,  /* c = 1 + 10.5/32 */ \
+    0x1.78a4c8178a4c8p-1, 0x1.3a64c556945eap-2,  /* c = 1 + 11.5/32 */ \
+    0x1.702e05c0b8170p-1, 0x1.51aad872df82ep-2,  /* c = 1 + 12.5/32 */ \
+    0x1.6816816816817p-1, 0x1.686c81e9b14adp-2,  /* c = 1 + 13.5/32 */ \
+    0x1.6058160581606p-1, 0x1.7eaf83b82afc2p-2,  /* c = 1 + 14.5/32 */ \
+    0x1.58ed2308158edp-1, 0x1.947941c2116fbp-2,  /* c = 1 + 15.5/32 */ \
+    0x1.51d07eae2f815p-1, 0x1.a9cec9a9a084ap-2,  /* c = 1 + 16.5/32 */ \
+    0x1.4afd6a052bf5bp-1, 0x1.beb4d9da71b7ap-2,  /* c = 1 + 17.5/32 */ \
+    0x1.446f86562d9fbp-1, 0x1.d32fe7e00ebd5p-2,  /* c = 1 + 18.5/32 */ \
+    0x1.3e22cbce4a902p-1, 0x1.e744261d68789p-2,  /* c = 1 + 19.5/32 */ \
+    0x1.3813813813814p-1, 0x1.faf588f78f31dp-2,  /* c = 1 + 20.5/32 */ \
+    0x1.323e34a2b10bfp-1, 0x1.0723e5c1cdf41p-1,  /* c = 1 + 21.5/32 */ \
+    0x1.2c9fb4d812ca0p-1, 0x1.109f39e2d4c96p-1,  /* c = 1 + 22.5/32 */ \
+    0x1.27350b8812735p-1, 0x1.19ee6b467c96fp-1,  /* c = 1 + 23.5/32 */ \
+    0x1.21fb78121fb78p-1, 0x1.23130d7bebf43p-1,  /* c = 1 + 24.5/32 */ \
+    0x1.1cf06ada2811dp-1, 0x1.2c0e9ed448e8cp-1,  /* c = 1 + 25.5/32 */ \
+    0x1.1811811811812p-1, 0x1.34e289d9ce1d2p-1,  /* c = 1 + 26.5/32 */ \
+    0x1.135c81135c811p-1, 0x1.3d9026a7156fbp-1,  /* c = 1 + 27.5/32 */ \
+    0x1.0ecf56be69c90p-1, 0x1.4618bc21c5ec2p-1,  /* c = 1 + 28.5/32 */ \
+    0x1.0a6810a6810a7p-1, 0x1.4e7d811b75bb0p-1,  /* c = 1 + 29.5/32 */ \
+    0x1.0624dd2f1a9fcp-1, 0x1.56bf9d5b3f399p-1,  /* c = 1 + 30.5/32 */ \
+    0x1.0204081020408p-1, 0x1.5ee02a9241676p-1,  /* c = 1 + 31.5/32 */ \
+}
+/* On the device the table lives in constant memory (and, for the kernels, as a copy in LDS: srt_powf_tab); host code of a HIP
+ * translation unit reads the _host copy — a __constant__ variable has no usable host value. */
 #if defined(__HIPCC__) || defined(__HIP__)
-#define SRT_TABLE __device__ __constant__ const
+__device__ __constant__ const double srt_pow_table[64] = SRT_POW_TABLE_INIT;
+static const double srt_pow_table_host[64] = SRT_POW_TABLE_INIT;
 #else
-#define SRT_TABLE static const
+static const double srt_pow_table[64] = SRT_POW_TABLE_INIT;
+#define srt_pow_table_host srt_pow_table
 #endif
-SRT_TABLE double srt_pow_table[64] = {
-    0x1.f81f81f81f820p-1, 0x1.fc0a8b0fc03c4p-7,  /* c = 1 + 0.5/32 */
-    0x1.e9131abf0b767p-1, 0x1.77458f632dcffp-5,  /* c = 1 + 1.5/32 */
-    0x1.dae6076b981dbp-1, 0x1.341d7961bd1d0p-4,  /* c = 1 + 2.5/32 */
-    0x1.cd85689039b0bp-1, 0x1.a926d3a4ad562p-4,  /* c = 1 + 3.5/32 */
-    0x1.c0e070381c0e0p-1, 0x1.0d77e7cd08e5bp-3,  /* c = 1 + 4.5/32 */
-    0x1.b4e81b4e81b4fp-1, 0x1.44d2b6ccb7d1cp-3,  /* c = 1 + 5.5/32 */
-    0x1.a98ef606a63bep-1, 0x1.7ab890210d907p-3,  /* c = 1 + 6.5/32 */
-    0x1.9ec8e951033d9p-1, 0x1.af3c94e80bff3p-3,  /* c = 1 + 7.5/32 */
-    0x1.948b0fcd6e9e0p-1, 0x1.e27076e2af2e8p-3,  /* c = 1 + 8.5/32 */
-    0x1.8acb90f6bf3aap-1, 0x1.0a324e27390e2p-2,  /* c = 1 + 9.5/32 */
-    0x1.8181818181818p-1, 0x1.22941fbcf7966p-2,  /* c = 1 + 10.5/32 */
-    0x1.78a4c8178a4c8p-1, 0x1.3a64c556945eap-2,  /* c = 1 + 11.5/32 */
-    0x1.702e05c0b8170p-1, 0x1.51aad872df82ep-2,  /* c = 1 + 12.5/32 */
-    0x1.6816816816817p-1, 0x1.686c81e9b14adp-2,  /* c = 1 + 13.5/32 */
-    0x1.6058160581606p-1, 0x1.7eaf83b82afc2p-2,  /* c = 1 + 14.5/32 */
-    0x1.58ed2308158edp-1, 0x1.947941c2116fbp-2,  /* c = 1 + 15.5/32 */
-    0x1.51d07eae2f815p-1, 0x1.a9cec9a9a084ap-2,  /* c = 1 + 16.5/32 */
-    0x1.4afd6a052bf5bp-1, 0x1.beb4d9da71b7ap-2,  /* c = 1 + 17.5/32 */
-    0x1.446f86562d9fbp-1, 0x1.d32fe7e00ebd5p-2,  /* c = 1 + 18.5/32 */
-    0x1.3e22cbce4a902p-1, 0x1.e744261d68789p-2,  /* c = 1 + 19.5/32 */
-    0x1.3813813813814p-1, 0x1.faf588f78f31dp-2,  /* c = 1 + 20.5/32 */
-    0x1.323e34a2b10bfp-1, 0x1.0723e5c1cdf41p-1,  /* c = 1 + 21.5/32 */
-    0x1.2c9fb4d812ca0p-1, 0x1.109f39e2d4c96p-1,  /* c = 1 + 22.5/32 */
-    0x1.27350b8812735p-1, 0x1.19ee6b467c96fp-1,  /* c = 1 + 23.5/32 */
-    0x1.21fb78121fb78p-1, 0x1.23130d7bebf43p-1,  /* c = 1 + 24.5/32 */
-    0x1.1cf06ada2811dp-1, 0x1.2c0e9ed448e8cp-1,  /* c = 1 + 25.5/32 */
-    0x1.1811811811812p-1, 0x1.34e289d9ce1d2p-1,  /* c = 1 + 26.5/32 */
-    0x1.135c81135c811p-1, 0x1.3d9026a7156fbp-1,  /* c = 1 + 27.5/32 */
-    0x1.0ecf56be69c90p-1, 0x1.4618bc21c5ec2p-1,  /* c = 1 + 28.5/32 */
-    0x1.0a6810a6810a7p-1, 0x1.4e7d811b75bb0p-1,  /* c = 1 + 29.5/32 */
-    0x1.0624dd2f1a9fcp-1, 0x1.56bf9d5b3f399p-1,  /* c = 1 + 30.5/32 */
-    0x1.0204081020408p-1, 0x1.5ee02a9241676p-1,  /* c = 1 + 31.5/32 */
-};
 
 /* x^y for x >= 0 (x<0 -> NaN), finite y > 0.  Covers every call the path makes:
  * powf(upd, 0.1f) with upd in (0,1] and powf(|upd|, .05f) with |upd| in [0,1].
@@ -135,7 +139,9 @@ SRT_TABLE double srt_pow_table[64] = {
  * fixed order: identical bits on x86 and gfx950.  Relative error before the final rounding < 2^-45, i.e. the
  * result is the correctly rounded x^y except for about one input in a million (tests/test_defs.py: <= 1 ulp
  * from libm's powf on EVERY float of (0,1] for both exponents). */
-SRT_HD float srt_powf(float xf, float yf) {
+/* `table`: the 32 (invc, lnc) pairs above — srt_pow_table itself, or a copy of its bytes somewhere cheaper to read (the kernels
+ * keep one in LDS next to the scene image; same values, same arithmetic, same bits). */
+SRT_HD float srt_powf_tab(float xf, float yf, const double* table) {
     srt_f32bits xb;
     xb.f = xf;
     if ((xb.u & 0x7fffffffU) > 0x7f800000U) return xf; /* NaN */
@@ -155,7 +161,7 @@ SRT_HD float srt_powf(float xf, float yf) {
     const int i = (int)((b.u >> 47) & 31U);
     b.u = (b.u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
     const double m = b.d;
-    const double s = SRT_FMA(m, srt_pow_table[2 * i], -1.0);
+    const double s = SRT_FMA(m, table[2 * i], -1.0);
     /* ln(1+s) = s + s^2 * (-1/2 + s/3 - s^2/4 + s^3/5 - s^4/6 + s^5/7) */
     double p = 1.0 / 7.0;
     p = SRT_FMA(p, s, -1.0 / 6.0);
@@ -167,7 +173,7 @@ SRT_HD float srt_powf(float xf, float yf) {
     const double LN2_HI = 6.93147180369123816490e-01; /* 0x3fe62e42fee00000: e * LN2_HI is exact */
     const double LN2_LO = 1.90821492927058770002e-10; /* 0x3dea39ef35793c76 */
     const double ed = (double)e;
-    const double lnx = SRT_FMA(ed, LN2_HI, srt_pow_table[2 * i + 1] + SRT_FMA(ed, LN2_LO, lnm));
+    const double lnx = SRT_FMA(ed, LN2_HI, table[2 * i + 1] + SRT_FMA(ed, LN2_LO, lnm));
     const double t = (double)yf * lnx;
 
     /* e^t = 2^k * e^r, |r| <= ln2/2, Taylor series through r^11 */
@@ -203,5 +209,7 @@ SRT_HD float srt_powf(float xf, float yf) {
     q = q * sc.d;
     return (float)q;
 }
+
+SRT_HD float srt_powf(float xf, float yf) { return srt_powf_tab(xf, yf, srt_pow_table); }
 
 #endif /* SRT_DEFS_H */

@@ -29,7 +29,8 @@ thread_local char g_create_error[512] = "";
 // (make -C software-raytracer_amd/csrc dev -> libsrt_pathtrace_dev.so, -DSRT_DEV) reads them from the
 // environment for in-process A/B timing (tests/ab_bench.py); all settings produce identical bits.
 #ifndef SRT_ORDER_MIN_WG
-#define SRT_ORDER_MIN_WG 512  // fewest blocks of tiles for which a launch records costs and is dispatched in cost order
+#define SRT_ORDER_MIN_WG 256  // fewest blocks of tiles for which a launch records costs and is dispatched in cost order (round 3: 512 -> 256,
+                              // the 48..64-row bands of a cost-balanced 8-rank 1080p frame: -4..-5 %)
 #endif
 struct DevSwitches {
     int kernel = 0;        // SRT_KERNEL: tuning variant
@@ -41,7 +42,6 @@ struct DevSwitches {
     int chunk_beta = 30;   // SRT_CHUNK_BETA (percent): sample chunks from recorded block costs, see srt_render
     bool host_order = true;  // SRT_HOST_ORDER=0: no host-derived initial dispatch order
     int kernel_flags = 0;    // SRT_KFLAGS: extra KernelParams.flags bits of timing experiments
-    bool one_kernel = true;  // SRT_ONE=0: one-sample launches through the pool kernel (A/B aid)
 };
 #ifdef SRT_DEV
 const DevSwitches& dev_switches() {
@@ -61,7 +61,6 @@ const DevSwitches& dev_switches() {
         d.chunk_beta = geti("SRT_CHUNK_BETA", 30);
         d.host_order = geti("SRT_HOST_ORDER", 1) != 0;
         d.kernel_flags = geti("SRT_KFLAGS", 0);
-        d.one_kernel = geti("SRT_ONE", 1) != 0;
         return d;
     }();
     return sw;
@@ -143,7 +142,6 @@ struct srt_context {
     uint64_t pending_samples = 0;
     uint32_t pending_chunks = 1;
     bool count_rays = false;
-    int one_parity = 0;  // which of the two work counters the next one-sample launch counts on
     int lds_limit_bytes = 64 * 1024;
     int cu_count = 256;
     bool scene_in_lds[2] = {true, true};  // per scene image: does it fit into LDS next to the scratch?
@@ -247,10 +245,7 @@ int srt_create(int device, int width, int height, srt_context** out) {
     const size_t px = (size_t)width * height;
     if ((e = hipMalloc((void**)&ctx->d_fb_own, px * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc framebuffer");
     if ((e = hipMalloc((void**)&ctx->d_acc_own, px * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc accumulator");
-    // [0] ray counter (SRT_RENDER_COUNT_RAYS), [1] the two work counters of the one-sample streaming kernel (zeroed here once; every
-    // launch uses one and leaves the other zeroed for the next launch, so no memset precedes a 0.15 ms kernel)
-    if ((e = hipMalloc((void**)&ctx->d_rays, 2 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc counter");
-    if ((e = hipMemsetAsync(ctx->d_rays, 0, 2 * sizeof(unsigned long long), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = hipMalloc((void**)&ctx->d_rays, sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc counter");
     if ((e = hipMalloc((void**)&ctx->d_pick, 4 * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc pick");
     if ((e = hipMemsetAsync(ctx->d_fb_own, 0, px * sizeof(uint32_t), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
     if ((e = hipMemsetAsync(ctx->d_acc_own, 0, px * sizeof(float4), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
@@ -320,6 +315,7 @@ static int set_scene_impl(srt_context* ctx, const srt_object* objects, size_t co
     for (int v = 0; v < 2; ++v) {
         // with meshes both images are the same one, so that primitive ids agree with the BVH
         srt::SceneLayout L = srt::build_scene_image(objects, count, (v == 0 || has_mesh) && !no_cluster, ctx->h_scene[v]);
+        srt::environment_rows(ctx->env, ctx->h_scene[v].data() + srt::SRT_CONST_ENV_ROW);
         // hit_key packs the list index in 15 bits and the primitive id in 16
         if (count >= 32768 || L.nsT + L.nb + L.nm >= 65536)
             return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: %zu objects (%d sphere slots + %d boxes + %d meshes) exceed the 32767-object limit",
@@ -428,6 +424,16 @@ int srt_set_meshes(srt_context* ctx, const srt_mesh* meshes, size_t count) {
 int srt_set_environment(srt_context* ctx, const srt_environment* env) {
     if (!ctx || !env) return SRT_ERR_INVALID_ARG;
     ctx->env = *env;
+    // the environment lives in the scene image's constants block (srt_scene_image.h): patch the uploaded images in place
+    if (ctx->scene_set) {
+        SRT_HIP(ctx, hipSetDevice(ctx->device));
+        SRT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (h_scene may still be the source of an upload in flight)
+        for (int v = 0; v < 2; ++v) {
+            float4* rows = ctx->h_scene[v].data() + srt::SRT_CONST_ENV_ROW;
+            srt::environment_rows(ctx->env, rows);
+            SRT_HIP(ctx, hipMemcpyAsync(ctx->d_scene[v] + srt::SRT_CONST_ENV_ROW, rows, 4 * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+        }
+    }
     return SRT_OK;
 }
 
@@ -487,11 +493,6 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
         K.right_rd[i] = c.right[i] * rd;
         K.up_ld[i] = c.up[i] * ld;
         K.fwd_clip[i] = c.forward[i] * clipDistance;
-        K.sun_dir[i] = ctx->env.sun_direction[i];
-        K.sky[i] = ctx->env.sky_color[i];
-        K.horizon[i] = ctx->env.horizon_color[i];
-        K.ground[i] = ctx->env.ground_color[i];
-        K.sun[i] = ctx->env.sun_color[i];
     }
     K.width = W;
     K.height = H;
@@ -517,7 +518,6 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
     const srt::SceneLayout& SL = ctx->layout[img];
     K.nu4 = SL.nu4;
     K.nu = SL.nu;
-    K.cluster_c1max = SL.cluster_c1max;
     K.nc = SL.nc;
     K.K = SL.K;
     K.nsT = SL.nsT;
@@ -580,39 +580,6 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
         ctx->cost_sum = 0.0;
         ctx->recording = false;
         ctx->order_gx = ctx->order_gy = 0;
-    }
-
-    // One sample per pixel at full resolution — the reference's own frame loop (Raytracer.cpp:572-595: every frame adds one
-    // sample) — runs the streaming kernel: resident waves pull 32 x 8 pixel chunks from a device counter and keep all 64 lanes
-    // on live paths until the launch runs out of pixels (srt_kernel.hip.h, pathtrace_one_kernel).  Same bits as the pool kernel.
-    if (p->sample_count == 1 && K.steps <= 1 && !(K.flags & SRT_RENDER_PREVIEW) && dev_switches().one_kernel) {
-        K.tile_h = srt::TILE_H;
-        const long long n_chunks = (long long)((W + srt::ONE_CHUNK_W - 1) / srt::ONE_CHUNK_W) * ((K.rows + srt::ONE_CHUNK_H - 1) / srt::ONE_CHUNK_H);
-        const int per_cu = K.n_tris > 0 ? 3 : 4;  // workgroups a CU holds (launch bounds + LDS)
-        const int waves_per_wg = srt::WG_TILES_X * srt::WG_TILES_Y;
-        long long wgs = (n_chunks + waves_per_wg - 1) / waves_per_wg;  // no more waves than chunks
-        if (wgs > (long long)per_cu * ctx->cu_count) wgs = (long long)per_cu * ctx->cu_count;
-        // launches of a context are ordered (one stream at a time): this one counts on counter `one_parity` and zeroes the other
-        unsigned* d_work = reinterpret_cast<unsigned*>(ctx->d_rays + 1) + ctx->one_parity;
-        unsigned* d_work_next = reinterpret_cast<unsigned*>(ctx->d_rays + 1) + (ctx->one_parity ^ 1);
-        ctx->one_parity ^= 1;
-        SRT_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
-        const dim3 g1((unsigned)wgs), b1(srt::WG_THREADS);
-        const bool lds1 = ctx->scene_in_lds[img];
-        if (K.n_tris > 0) {
-            if (lds1) hipLaunchKernelGGL((srt::pathtrace_one_kernel<3, true, true>), g1, b1, lds_bytes, ctx->stream, K, d_work, d_work_next);
-            else hipLaunchKernelGGL((srt::pathtrace_one_kernel<3, true, false>), g1, b1, lds_bytes, ctx->stream, K, d_work, d_work_next);
-        } else {
-            if (lds1) hipLaunchKernelGGL((srt::pathtrace_one_kernel<4, false, true>), g1, b1, lds_bytes, ctx->stream, K, d_work, d_work_next);
-            else hipLaunchKernelGGL((srt::pathtrace_one_kernel<4, false, false>), g1, b1, lds_bytes, ctx->stream, K, d_work, d_work_next);
-        }
-        SRT_HIP(ctx, hipGetLastError());
-        SRT_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
-        ctx->launched = true;
-        ctx->stats_pending = true;
-        ctx->pending_samples = (uint64_t)W * (uint64_t)K.rows;
-        ctx->pending_chunks = 1;
-        return SRT_OK;
     }
 
     // Tile height: with few rows and many samples per pixel (a narrow stripe of a multi-GPU frame) 8-row

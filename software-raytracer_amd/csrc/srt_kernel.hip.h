@@ -57,8 +57,7 @@ struct KernelParams {
     float right_rd[3];  // cameraTransform.right * rd          (Raytracer.cpp:114,116)
     float up_ld[3];     // cameraTransform.up * ld             (:115,117)
     float fwd_clip[3];  // cameraTransform.forward * clipDist  (:113)
-    float sun_dir[3];
-    float sky[3], horizon[3], ground[3], sun[3];
+    // (the environment of Raytracer.cpp:55-59 travels in the scene image's constants block, srt_scene_image.h)
     int32_t width, height;
     int32_t y0, rows;  // scene rows [y0, y0+rows)
     uint32_t first_sample, sample_count;
@@ -69,7 +68,6 @@ struct KernelParams {
     // scene image layout (srt_scene_image.h)
     int32_t nu4, nc, K, nsT, nb;
     int32_t nu;  // uniform spheres that are not padding
-    float cluster_c1max;  // max over the cluster bounds of |C|_1, rounded up (distance cull of closest_hit)
     int32_t off_bounds, off_box, off_mat;
     int32_t scene_vec4;  // number of float4 in the scene image
     const float4* scene;
@@ -154,6 +152,11 @@ __device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v) {
     return v;
 }
 __device__ __forceinline__ float clamp0(float v) { return v < 0 ? 0.0f : v; }  // Common.hpp:254-257
+// Where a clamp0 of the reference is NOT spelled out below ("NN"): clamp0 changes strictly negative values only (-0 and NaN pass),
+// and a sum or product of values that are never strictly negative is never strictly negative either.  The material colours and
+// the environment colours arrive clamped in the scene image (srt_scene_image.h), spec is 0 or 1, the weights of the running mean
+// lie in [0, 1]; so L, T, sample colours and every accumulator after its first fold are NN and the reference's clamp of such a
+// sum or product is the identity — two instructions and a VCC hazard each, about a third of the shading code before.
 
 // (float)rand() / RAND_MAX (Raytracer.cpp:93-95,165,182) for r in [0, 32767]: the correctly rounded
 // quotient via one Newton correction (q0 = r*y, e = fma(-q0, b, r), q = fma(e, y, q0)) instead of
@@ -166,20 +169,37 @@ __device__ __forceinline__ float rand_unit(uint32_t r) {
     return __builtin_fmaf(__builtin_fmaf(-q0, b, a), y, q0);
 }
 
+// sqrtf, correctly rounded (Object.hpp:131, Common.hpp:159): v_sqrt_f32 is good to one ulp; the two neighbours' residuals
+// x - s' * s (exact in an FMA) say which of the three is the rounded root — the very sequence hipcc emits for sqrtf, minus its
+// rescaling of tiny arguments and its pass-through of 0 / inf, neither of which the sequence needs: for +-0, +inf and NaN the
+// residual tests come out false and v_sqrt_f32's own result stands.  Arguments in (0, 2^-96), where v_sqrt_f32's accuracy is
+// not specified, take hipcc's general sqrtf (one wave-uniform branch, in practice never taken).  11 instructions instead of 20.
+__device__ __forceinline__ float sqrt_rn(float x) {
+    if (__builtin_amdgcn_ballot_w64(__float_as_uint(x) - 1u < 0x0F800000u - 1u) != 0ull) return sqrtf(x);  // some lane: 0 < x < 2^-96
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __int_as_float(__float_as_int(s) - 1), s_up = __int_as_float(__float_as_int(s) + 1);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+    s = r_dn <= 0.0f ? s_dn : s;
+    s = r_up > 0.0f ? s_up : s;
+    return s;
+}
+
 struct V3 {
     float x, y, z;
 };
 __device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
 // float3::Normalized (Common.hpp:159-162)
 __device__ __forceinline__ V3 normalized(V3 a) {
-    float length = sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z);
+    float length = sqrt_rn((a.x * a.x + a.y * a.y) + a.z * a.z);
     return v3(a.x / length, a.y / length, a.z / length);
 }
 __device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 
 
+constexpr int CONST_ROWS = 36, CONST_ENV_ROW = 32;  // srt_scene_image.h: SRT_CONST_ROWS / SRT_CONST_ENV_ROW
 struct Lds {
-    const float4* v;  // LDS base
+    const float4* c;  // the image's constants block: srt_powf's table (32 rows), the environment (4 rows)
+    const float4* v;  // the primitives behind it (all offsets below count from here)
     int nu4, nu, nc, K, nsT, nb, off_bounds, off_box, off_mat;
     unsigned long long* res;  // this wave's 64 result slots
     unsigned short* work;     // this wave's work list
@@ -300,7 +320,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
     };
     auto part2 = [&](const Cand& k, int p, float& tb, int& pb) {
         if (__builtin_amdgcn_ballot_w64(k.c) != 0ull) {
-            float t1 = k.tc - sqrtf(k.x);  // :131-133
+            float t1 = k.tc - sqrt_rn(k.x);  // :131-133
             // Raytracer.cpp:130-132; on an exact tie the earlier entry of ObjectsToRender wins.
             // Branch-free on purpose (see the note in the triangle phase).
             const bool tie = k.c & (t1 == tb) & (pb >= 0);
@@ -344,44 +364,12 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
         }
     }
     SRT_TICK(3);
-    // ---- 2. boxes (before the clusters: in a closed room every ray meets a wall, and the clusters beyond that distance are
-    // then not even candidates, see the bound test below)
-    Hit h;
-    V3 bt1 = v3(0, 0, 0);
-    BoxRay br;
-    const int nsT = S.nsT, nb = S.nb;
-    if (nb > 0) {
-        br = box_ray_setup(d);
-        for (int j = 0; j < nb; ++j) {
-            const float4 c = S.box_c(j), hs = S.box_h(j);
-            V3 t1;
-            float dist = ibox_dist(br, v3(o.x - c.x, o.y - c.y, o.z - c.z), v3(hs.x, hs.y, hs.z), t1);
-            bool valid = active && dist != 3.402823466e+38f;  // Object.hpp:231
-            if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
-                const bool tie = valid & (dist == best) & (bp >= 0);
-                bool win = valid & (dist < best);
-                if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // rare: list indices only on an exact tie
-                    const int ob = S.order(tie ? bp : nsT + j);
-                    win = win | (tie & (S.order(nsT + j) < ob));
-                }
-                best = win ? dist : best;
-                bp = win ? nsT + j : bp;
-                // component-wise: a whole-struct select is lowered to a pointer select + copies through scratch
-                bt1 = v3(win ? t1.x : bt1.x, win ? t1.y : bt1.y, win ? t1.z : bt1.z);
-            }
-        }
-    }
-    // ---- 3. clustered spheres
+    // ---- 2. clustered spheres
     if (S.nc > 0) {
         const float dd = __builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x));
         const bool unit = fabsf(dd - 1.0f) <= 1e-6f;  // false for NaN
         if (__builtin_amdgcn_ballot_w64(active && !unit) == 0ull) {
             const float o1 = (fabsf(o.x) + fabsf(o.y)) + fabsf(o.z);
-            // A member sphere's recorded distance is t1 = |L.d| - sqrt(r^2 - d2) >= |L.d| - r (also for the mirrored sphere behind
-            // the ray and for negative distances), and |L.d| >= |(C - o).d| - |c - C|, so t1 >= |s| - R_geo; in binary32, with the
-            // rounding of L, of the dot product, of the root and of s itself: t1 >= |sd| - Rg - 2e-6 * |C - o|, and
-            // |C - o| <= |o|_1 + max |C|_1.  A cluster with |sd| - Rg beyond best + that slack cannot win, nor tie.
-            const float far = __builtin_fmaf(2e-6f, o1 + P.cluster_c1max, best);  // (+inf while nothing has been hit)
             unsigned long long mask = 0ull;
             for (int k = 0; k < S.nc; ++k) {  // phase 1: conservative cluster bounds, uniform reads
                 const float4 b = S.bound(k);
@@ -391,7 +379,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                 float Rinf = __builtin_fmaf(8e-6f, o1, b.w);
                 float lhs = __builtin_fmaf(-sd, sd, LL);
                 float rhs = __builtin_fmaf(4e-6f, LL, Rinf * Rinf);
-                if ((lhs <= rhs) & (fabsf(sd) - b.w <= far)) mask |= 1ull << k;
+                if (lhs <= rhs) mask |= 1ull << k;
             }
             if (!active) mask = 0ull;
             n_cand = __builtin_popcountll(mask);
@@ -462,6 +450,35 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
         }
     }
     SRT_TICK(5);
+    // ---- 3. boxes
+    // (Tried in round 3 and dropped: boxes BEFORE the clusters plus a cull of clusters whose nearest possible hit, |s| - R - slack,
+    // lies beyond the best distance so far — valid, all tests bit-exact, but the two extra instructions per bound cost more than
+    // the culled exact tests saved: Scene_indirect +1.4 %, Scene1 +2.3 %, config 4 +3.4 %.)
+    Hit h;
+    V3 bt1 = v3(0, 0, 0);
+    BoxRay br;
+    const int nsT = S.nsT, nb = S.nb;
+    if (nb > 0) {
+        br = box_ray_setup(d);
+        for (int j = 0; j < nb; ++j) {
+            const float4 c = S.box_c(j), hs = S.box_h(j);
+            V3 t1;
+            float dist = ibox_dist(br, v3(o.x - c.x, o.y - c.y, o.z - c.z), v3(hs.x, hs.y, hs.z), t1);
+            bool valid = active && dist != 3.402823466e+38f;  // Object.hpp:231
+            if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
+                const bool tie = valid & (dist == best) & (bp >= 0);
+                bool win = valid & (dist < best);
+                if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // rare: list indices only on an exact tie
+                    const int ob = S.order(tie ? bp : nsT + j);
+                    win = win | (tie & (S.order(nsT + j) < ob));
+                }
+                best = win ? dist : best;
+                bp = win ? nsT + j : bp;
+                // component-wise: a whole-struct select is lowered to a pointer select + copies through scratch
+                bt1 = v3(win ? t1.x : bt1.x, win ? t1.y : bt1.y, win ? t1.z : bt1.z);
+            }
+        }
+    }
     // ---- 4. EXTENSION: triangle meshes — traversal of the host-built 8-wide BVH (HBM/L2).
     // The triangle arithmetic is this project's definition (srt_pathtrace.h); the box filter is
     // conservative: boxes are padded per ray by 1e-5 * (|o - centre|_1 + |centre|_1 + mesh size), a
@@ -862,28 +879,30 @@ __device__ __forceinline__ RGB color_lerp(RGB a, RGB b, float t) {
     return RGB{clamp0(a.r * (1 - t) + b.r * t), clamp0(a.g * (1 - t) + b.g * t), clamp0(a.b * (1 - t) + b.b * t)};
 }
 
-// GetEnvironmentColor (Raytracer.cpp:77-89)
-__device__ __forceinline__ RGB environment(const KernelParams& P, V3 d) {
-    RGB Sky{clamp0(P.sky[0]), clamp0(P.sky[1]), clamp0(P.sky[2])};
-    RGB Horizon{clamp0(P.horizon[0]), clamp0(P.horizon[1]), clamp0(P.horizon[2])};
-    RGB Ground{clamp0(P.ground[0]), clamp0(P.ground[1]), clamp0(P.ground[2])};
+// GetEnvironmentColor (Raytracer.cpp:77-89).  The four colours arrive clamped (Color's constructor, Common.hpp:253-262) in
+// the image's constants block, next to srt_powf's table: LDS reads, no kernel-argument registers, no constant-memory trips.
+__device__ __forceinline__ RGB environment(const Lds& S, V3 d) {
+    const float4 e0 = S.c[CONST_ENV_ROW], e1 = S.c[CONST_ENV_ROW + 1], e2 = S.c[CONST_ENV_ROW + 2], e3 = S.c[CONST_ENV_ROW + 3];
+    RGB Sky{e0.x, e0.y, e0.z};
+    RGB Horizon{e1.x, e1.y, e1.z};
+    RGB Ground{e2.x, e2.y, e2.z};
     float upd = (d.x * 0.0f + d.y * 1.0f) + d.z * 0.0f;  // Dot(rayDirection, WORLDUP) :78
-    float sd = (d.x * (P.sun_dir[0] * -1) + d.y * (P.sun_dir[1] * -1)) + d.z * (P.sun_dir[2] * -1);
+    float sd = (d.x * (e3.x * -1) + d.y * (e3.y * -1)) + d.z * (e3.z * -1);
     bool sunny = (double)sd > 0.99;  // :79 float vs double literal
-    RGB Sun{sunny ? clamp0(P.sun[0]) : 0.0f, sunny ? clamp0(P.sun[1]) : 0.0f, sunny ? clamp0(P.sun[2]) : 0.0f};
+    RGB Sun{sunny ? e0.w : 0.0f, sunny ? e1.w : 0.0f, sunny ? e2.w : 0.0f};
     // one srt_powf call site for both branches (:81 powf(upd, 0.1f) / :87 powf(|upd|, .05f)):
     // the arguments are selected per lane, so up- and down-going lanes do not serialize.
     const bool up = upd > 0;
-    const float pw = srt_powf(up ? upd : fabsf(upd), up ? 0.1f : .05f);
+    const float pw = srt_powf_tab(up ? upd : fabsf(upd), up ? 0.1f : .05f, reinterpret_cast<const double*>(S.c));
     RGB t;
     if (up) {
         t = color_lerp(Horizon, Sky, pw);  // :81
-        RGB sky01{clamp0(Sky.r * 0.1f), clamp0(Sky.g * 0.1f), clamp0(Sky.b * 0.1f)};
+        RGB sky01{Sky.r * 0.1f, Sky.g * 0.1f, Sky.b * 0.1f};  // (NN)
         t = color_lerp(t, sky01, upd);     // :82
     } else {
         t = color_lerp(Horizon, Ground, pw);  // :86-87
     }
-    return RGB{clamp0(t.r + Sun.r), clamp0(t.g + Sun.g), clamp0(t.b + Sun.b)};  // :83 / :87
+    return RGB{t.r + Sun.r, t.g + Sun.g, t.b + Sun.b};  // :83 / :87 (NN: t comes out of Color::Lerp's clamp)
 }
 
 // (int)f with x86 cvttss2si semantics (reference platform), see oracle cvtt_x86
@@ -909,18 +928,20 @@ __device__ __forceinline__ void accumulate_sample(const KernelParams& P, float4&
         // of a binary32 rounding boundary unless it is exact; checked exhaustively in tests).
         float weight = frame <= 16777216u ? 1.0f / (float)(int)frame : (float)(1.0 / (double)(int)frame);
         float om = 1 - weight;
-        acc.x = clamp0(clamp0(acc.x * om) + clamp0(c.r * weight));  // :67
-        acc.y = clamp0(clamp0(acc.y * om) + clamp0(c.g * weight));
-        acc.z = clamp0(clamp0(acc.z * om) + clamp0(c.b * weight));
-        acc.w = clamp0(clamp0(acc.w * om) + clamp0(0.0f * weight));
+        // :67; the accumulator may come from the caller (srt_write_accumulator): its product keeps the clamp, the rest is NN
+        acc.x = clamp0(acc.x * om) + c.r * weight;
+        acc.y = clamp0(acc.y * om) + c.g * weight;
+        acc.z = clamp0(acc.z * om) + c.b * weight;
+        acc.w = clamp0(acc.w * om) + 0.0f * weight;
     }
 }
 // SetScreenPixel tone-map + pack + the two stores (Raytracer.cpp:64,73-75)
 __device__ __forceinline__ uint32_t tone_map(const float4 acc) {
-    float r = clamp0(acc.x / clamp0(1.0f + acc.x));
-    float g = clamp0(acc.y / clamp0(1.0f + acc.y));
-    float b = clamp0(acc.z / clamp0(1.0f + acc.z));
-    float a = clamp0(acc.w / clamp0(0.0f + acc.w));
+    // (every accumulator that gets here has been through accumulate_sample or is a sample colour: NN)
+    float r = acc.x / (1.0f + acc.x);
+    float g = acc.y / (1.0f + acc.y);
+    float b = acc.z / (1.0f + acc.z);
+    float a = acc.w / (0.0f + acc.w);
     return pack_channel(a) << 24 | pack_channel(r) << 16 | pack_channel(g) << 8 | pack_channel(b);
 }
 __device__ __forceinline__ void store_pixel(const KernelParams& P, uint32_t pix, const float4 acc) {
@@ -943,7 +964,7 @@ __device__ __forceinline__ Lds make_lds(const KernelParams& P, float4* lds, int 
         image = lds;
     else
         image = P.scene;
-    return Lds{image, P.nu4, P.nu, P.nc, P.K, P.nsT, P.nb, P.off_bounds, P.off_box, P.off_mat,
+    return Lds{image, image + CONST_ROWS, P.nu4, P.nu, P.nc, P.K, P.nsT, P.nb, P.off_bounds, P.off_box, P.off_mat,
                reinterpret_cast<unsigned long long*>(scratch), reinterpret_cast<unsigned short*>(scratch + 64 * 8),
                reinterpret_cast<float*>(scratch + 64 * 8 + WORK_MAX * 2),
                reinterpret_cast<float4*>(scratch + 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4),
@@ -1137,11 +1158,11 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     if (in_range && !pix_traced && (!DEFER || blockIdx.z == 0)) {  // (chunked: once, by the first chunk, for all samples)
         RGB c;
         if (h0.prim < 0) {
-            c = environment(P, dir0);
+            c = environment(S, dir0);
         } else if (preview) {
             float4 m0 = S.mat(h0.prim, 0), m1 = S.mat(h0.prim, 1);
             float k2 = 2 * dot3(dir0, h0.n);  // rayDirection.Reflect(normal), Common.hpp:163-165
-            RGB refl = environment(P, v3(dir0.x - h0.n.x * k2, dir0.y - h0.n.y * k2, dir0.z - h0.n.z * k2));  // :148
+            RGB refl = environment(S, v3(dir0.x - h0.n.x * k2, dir0.y - h0.n.y * k2, dir0.z - h0.n.z * k2));  // :148
             const float k = m0.y, sm = m0.x;  // :149-150
             float fresnal = 0;
             if (S.order(h0.prim) == P.selected) {  // :153
@@ -1251,7 +1272,6 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         uint32_t own_next = own_done;
         int rot = 0;  // wave-uniform rotation of the slot priority
         const int fold_pace = (63 + n_hit) / n_hit;
-        const int max_pass = MULTI ? 2 : (n_hit >= 32 ? 2 : (n_hit >= 16 ? 4 : 8));
 
         while (true) {
             SRT_TICK(7);
@@ -1315,9 +1335,10 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             // free lanes than such slots, the lanes are dealt round-robin to the slots and a slot hands out
             // as many consecutive samples as it is dealt lanes, up to its capacity — so a small tile
             // (P.tile_h) still keeps all 64 lanes busy
-            // (two passes keep a well-filled tile busy; a tile with few traced pixels needs more — every pass starts at most one
-            // sample per slot — or most of its lanes never work: up to 8 passes below 16 slots, 4 below 32)
-            for (int pass = 0; pass < max_pass; ++pass) {
+            // (Two passes.  Tried in round 3: up to 8 passes for tiles with fewer than 16 traced pixels, 4 below 32 — every pass
+            // starts at most one sample per slot, so such a tile keeps few lanes busy — but on whole frames and on the 135-row
+            // bands of config 3 it was 0.4..2 % slower: the sparse tiles are too few, the longer loop costs everyone.)
+            for (int pass = 0; pass < 2; ++pass) {
                 const unsigned long long freem = __builtin_amdgcn_ballot_w64(!busy);
                 const uint32_t lim = count < own_done + (uint32_t)depth ? count : own_done + (uint32_t)depth;
                 const int avail = own_next < lim ? (int)(lim - own_next) : 0;
@@ -1366,8 +1387,8 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                     rng += 0x9E3779B9U;
                     float4 m0 = S.mat(prim0, 0), m1 = S.mat(prim0, 1);
                     spec = (m0.y >= rand_unit(rr)) ? 1.0f : 0.0f;  // :165
-                    L = RGB{clamp0(m1.y), clamp0(m1.z), clamp0(m1.w)};                 // :162
-                    T = RGB{clamp0(m0.z), clamp0(m0.w), clamp0(m1.x)};                 // :163
+                    L = RGB{m1.y, m1.z, m1.w};                                         // :162 (clamped in the image)
+                    T = RGB{m0.z, m0.w, m1.x};                                         // :163
                     sray = v3(r[0], r[1], r[2]);                                       // :164
                     hn = v3(r[3], r[4], r[5]);
                     hp = v3(r[6], r[7], r[8]);
@@ -1392,7 +1413,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 o = v3(hp.x + hn.x * ofs, hp.y + hn.y * ofs, hp.z + hn.z * ofs);
             } else if (busy) {
                 if (bounce != 0) {  // :169-171
-                    T = RGB{clamp0(T.r * 0.8f), clamp0(T.g * 0.8f), clamp0(T.b * 0.8f)};
+                    T = RGB{T.r * 0.8f, T.g * 0.8f, T.b * 0.8f};  // (NN)
                 }
                 // reflectedRay = sray.Reflect(normal)  (:172, Common.hpp:163-165)
                 float k2 = 2 * dot3(sray, hn);
@@ -1418,19 +1439,20 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 ++rays;
                 bool end_path;
                 if (h.prim < 0) {  // :178-181
-                    RGB e = environment(P, sray);
-                    L = RGB{clamp0(L.r + clamp0(e.r * T.r)), clamp0(L.g + clamp0(e.g * T.g)), clamp0(L.b + clamp0(e.b * T.b))};
+                    RGB e = environment(S, sray);
+                    L = RGB{L.r + e.r * T.r, L.g + e.g * T.g, L.b + e.b * T.b};  // (NN)
                     end_path = true;
                 } else {
                     float4 m0 = S.mat(h.prim, 0), m1 = S.mat(h.prim, 1), m2 = S.mat(h.prim, 2);
                     uint32_t r = srt_mix32(rng) >> 17;
                     rng += 0x9E3779B9U;
                     spec = (m0.y >= rand_unit(r)) ? 1.0f : 0.0f;  // :182
-                    RGB Em{clamp0(m1.y), clamp0(m1.z), clamp0(m1.w)};
-                    L = RGB{clamp0(L.r + clamp0(Em.r * T.r)), clamp0(L.g + clamp0(Em.g * T.g)), clamp0(L.b + clamp0(Em.b * T.b))};  // :183
-                    RGB Bc{clamp0(m0.z), clamp0(m0.w), clamp0(m1.x)}, Sc{clamp0(m2.x), clamp0(m2.y), clamp0(m2.z)};
-                    RGB f = color_lerp(Bc, Sc, spec);                                   // :184
-                    T = RGB{clamp0(T.r * f.r), clamp0(T.g * f.g), clamp0(T.b * f.b)};
+                    RGB Em{m1.y, m1.z, m1.w};
+                    L = RGB{L.r + Em.r * T.r, L.g + Em.g * T.g, L.b + Em.b * T.b};  // :183 (NN)
+                    RGB Bc{m0.z, m0.w, m1.x}, Sc{m2.x, m2.y, m2.z};
+                    const float ns = 1 - spec;                                          // :184, Color::Lerp with t = 0 or 1 (NN)
+                    RGB f{Bc.r * ns + Sc.r * spec, Bc.g * ns + Sc.g * spec, Bc.b * ns + Sc.b * spec};
+                    T = RGB{T.r * f.r, T.g * f.g, T.b * f.b};
                     hn = h.n;
                     hp = h.p;
                     hprim = h.prim;
@@ -1490,170 +1512,15 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     }
 }
 
-// ---- one-sample launches: the reference's own frame loop adds ONE sample per frame (Raytracer.cpp:572-595) ---------------
-// With one sample per pixel there is nothing to keep in order — the pixel's one colour is folded into its running mean by
-// whichever lane finishes the path — and nothing to reuse (the primary hit serves one sample).  So this kernel streams:
-// resident waves pull chunks of 256 pixels (a 32 x 8 strip) from a counter in device memory; a free lane takes the next pixel of
-// its wave's chunk and traces the path from the PRIMARY ray on; every step all busy lanes — primary and bounce rays alike — go
-// through one cooperative closest_hit; a lane whose path ends accumulates, tone-maps and stores its pixel and is free again.
-// The wave stays full until the launch runs out of pixels: one thin tail per launch, where pathtrace_kernel's pool (64 pixels,
-// one sample each) thins out per wave — a wave kept its tile until the longest of 64 paths ended.  Same arithmetic, same
-// random stream (keyed by pixel and sample), same bits.
-constexpr int ONE_CHUNK_W = 32, ONE_CHUNK_H = 8, ONE_CHUNK = ONE_CHUNK_W * ONE_CHUNK_H;
-template <int MIN_WAVES, bool MESH, bool SCENE_LDS>
-__global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_one_kernel(const KernelParams P, unsigned* work_counter, unsigned* next_launch_counter) {
-    extern __shared__ float4 lds_scene[];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *next_launch_counter = 0u;  // (nothing reads it before the next launch of this context)
-#if defined(SRT_STATS) && SRT_STATS == 3
-    Prof prof;
-    prof.last = (long long)__builtin_readcyclecounter();
-    for (int i = 0; i < 8; ++i) prof.acc[i] = 0;
-#endif
-    if constexpr (SCENE_LDS) {
-        for (int i = threadIdx.x; i < P.scene_vec4; i += WG_THREADS) lds_scene[i] = P.scene[i];
-        __syncthreads();
-    }
-    const Lds S = make_lds<SCENE_LDS>(P, lds_scene, WG_TILES_X * WG_TILES_Y, threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int W = P.width;
-    const int strips_x = (W + ONE_CHUNK_W - 1) / ONE_CHUNK_W, strips_y = (P.rows + ONE_CHUNK_H - 1) / ONE_CHUNK_H;
-    const unsigned n_chunks = (unsigned)(strips_x * strips_y);
-    const int B = P.max_bounces;
-    const V3 cam = v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
-    const float ofs = .00001f;
-
-    // the wave's chunk (wave-uniform) and how far it has been handed out
-    int cx0 = 0, cy0 = 0, c_next = ONE_CHUNK;
-    bool more = true;  // the launch may still have chunks
-    // this lane's path
-    bool busy = false, primary = false, parked = false;
-    uint32_t pixel = 0;
-    RGB L{0, 0, 0}, T{0, 0, 0};
-    V3 sray = v3(0, 0, 1), hn = v3(0, 0, 0), hp = v3(0, 0, 0);
-    int hprim = 0, bounce = 0;
-    float spec = 0.0f;
-    uint32_t rng = 0;
-    unsigned rays = 0;
-
-    while (true) {
-        SRT_TICK(7);
-        // ---- hand out pixels to the free lanes: the i-th free lane takes the chunk's (c_next + i)-th pixel
-        for (int pass = 0; pass < 2; ++pass) {
-            const unsigned long long freem = __builtin_amdgcn_ballot_w64(!busy);
-            if (freem == 0ull) break;
-            if (c_next >= ONE_CHUNK) {
-                if (!more) break;
-                unsigned c = 0;
-                if (lane == 0) c = atomicAdd(work_counter, 1u);
-                c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
-                if (c >= n_chunks) {
-                    more = false;
-                    break;
-                }
-                const int sy = (int)(c / (unsigned)strips_x);
-                cx0 = ((int)c - sy * strips_x) * ONE_CHUNK_W, cy0 = sy * ONE_CHUNK_H;
-                c_next = 0;
-            }
-            const int nfree = __builtin_popcountll(freem);
-            const int frank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(freem >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)freem, 0u));
-            const int l = c_next + frank;  // 8 x 8 tiles side by side: pixel l of the chunk is pixel l & 63 of tile l >> 6
-            c_next += nfree;
-            if (!busy && l < ONE_CHUNK) {
-                const int x = cx0 + (l >> 6) * TILE_W + (l & (TILE_W - 1)), ty = cy0 + ((l >> 3) & (TILE_H - 1));
-                if (x < W && ty < P.rows) {
-                    const int y = P.y0 + ty;
-                    pixel = (uint32_t)(x + y * W);
-                    // GetRayDirection (Raytracer.cpp:106-122)
-                    float nX = ((float)x / (float)W) * 2 - 1;
-                    float nY = ((float)y / (float)P.height) * 2 - 1;
-                    V3 u = v3(P.right_rd[0] * nX, P.right_rd[1] * nX, P.right_rd[2] * nX);
-                    V3 vv = v3(P.up_ld[0] * nY, P.up_ld[1] * nY, P.up_ld[2] * nY);
-                    sray = normalized(v3((u.x + vv.x) + P.fwd_clip[0], (u.y + vv.y) + P.fwd_clip[1], (u.z + vv.z) + P.fwd_clip[2]));
-                    busy = true, primary = true, parked = false;
-                }
-            }
-        }
-        if (__builtin_amdgcn_ballot_w64(busy) == 0ull) {
-            if (!more && c_next >= ONE_CHUNK) break;  // no pixel left anywhere for this wave
-            continue;
-        }
-        SRT_TICK(1);
-        // ---- the ray of every busy lane: the primary ray, or one bounce (Raytracer.cpp:169-177)
-        V3 o = v3(0, 0, 0);
-        if (busy && primary) {
-            o = cam;
-        } else if (MESH && busy && parked) {  // the ray made earlier, offered to the mesh phase again
-            o = v3(hp.x + hn.x * ofs, hp.y + hn.y * ofs, hp.z + hn.z * ofs);
-        } else if (busy) {
-            if (bounce != 0) {  // :169-171
-                T = RGB{clamp0(T.r * 0.8f), clamp0(T.g * 0.8f), clamp0(T.b * 0.8f)};
-            }
-            float k2 = 2 * dot3(sray, hn);  // :172, Common.hpp:163-165
-            V3 refl = v3(sray.x - hn.x * k2, sray.y - hn.y * k2, sray.z - hn.z * k2);
-            uint32_t r0 = srt_mix32(rng) >> 17;  // :90-105: exactly three draws, x then y then z
-            uint32_t r1 = srt_mix32(rng + 0x9E3779B9U) >> 17;
-            uint32_t r2 = srt_mix32(rng + 2u * 0x9E3779B9U) >> 17;
-            rng += 3u * 0x9E3779B9U;
-            V3 sr = v3((rand_unit(r0) - 0.5f) * 2, (rand_unit(r1) - 0.5f) * 2, (rand_unit(r2) - 0.5f) * 2);
-            sr = normalized(sr);
-            if (dot3(sr, hn) < 0) sr = v3(sr.x * -1, sr.y * -1, sr.z * -1);
-            float tt = S.mat(hprim, 0).x * spec;  // :175
-            V3 l = v3(sr.x * (1 - tt) + refl.x * tt, sr.y * (1 - tt) + refl.y * tt, sr.z * (1 - tt) + refl.z * tt);
-            sray = normalized(l);  // :176
-            o = v3(hp.x + hn.x * ofs, hp.y + hn.y * ofs, hp.z + hn.z * ofs);  // :177
-        }
-        const Hit h = closest_hit<MESH>(S, P, o, sray, busy, P.mesh_defer, parked SRT_PROF_ARG);
-        if (busy && !(MESH && parked)) {
-            ++rays;
-            bool end_path;
-            if (h.prim < 0) {  // :143-145 (primary) / :178-181
-                RGB e = environment(P, sray);
-                L = primary ? e : RGB{clamp0(L.r + clamp0(e.r * T.r)), clamp0(L.g + clamp0(e.g * T.g)), clamp0(L.b + clamp0(e.b * T.b))};
-                end_path = true;
-            } else {
-                float4 m0 = S.mat(h.prim, 0), m1 = S.mat(h.prim, 1), m2 = S.mat(h.prim, 2);
-                if (primary) rng = srt_rng_key(P.seed, pixel, P.first_sample);
-                uint32_t r = srt_mix32(rng) >> 17;
-                rng += 0x9E3779B9U;
-                spec = (m0.y >= rand_unit(r)) ? 1.0f : 0.0f;  // :165 / :182
-                RGB Em{clamp0(m1.y), clamp0(m1.z), clamp0(m1.w)}, Bc{clamp0(m0.z), clamp0(m0.w), clamp0(m1.x)};
-                if (primary) {  // :162-163
-                    L = Em;
-                    T = Bc;
-                    bounce = 0;
-                    end_path = B <= 0;
-                } else {
-                    L = RGB{clamp0(L.r + clamp0(Em.r * T.r)), clamp0(L.g + clamp0(Em.g * T.g)), clamp0(L.b + clamp0(Em.b * T.b))};  // :183
-                    RGB Sc{clamp0(m2.x), clamp0(m2.y), clamp0(m2.z)};
-                    RGB f = color_lerp(Bc, Sc, spec);  // :184
-                    T = RGB{clamp0(T.r * f.r), clamp0(T.g * f.g), clamp0(T.b * f.b)};
-                    ++bounce;
-                    end_path = bounce >= B;
-                }
-                hn = h.n;
-                hp = h.p;
-                hprim = h.prim;
-            }
-            primary = false;
-            if (end_path) {  // SetScreenPixel (:63-76) for this pixel's one sample
-                float4 acc = (P.flags & 1u) ? make_float4(0, 0, 0, 0) : P.accumulator[pixel];
-                accumulate_sample(P, acc, L, 0);
-                store_pixel(P, pixel, acc);
-                busy = false;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-#if defined(SRT_STATS) && SRT_STATS == 3
-    SRT_TICK(7);
-    for (int i = 0; i < 8; ++i) SRT_STAT(i, prof.acc[i] > 0 ? prof.acc[i] : 0);
-#endif
-    if (P.flags & 2u) {  // SRT_RENDER_COUNT_RAYS
-        unsigned long long tot = rays;
-        for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
-        if (lane == 0 && tot) atomicAdd(P.ray_counter, tot);
-    }
-}
+// ---- one-sample launches (the reference's own frame loop adds ONE sample per frame, Raytracer.cpp:572-595) run through
+// pathtrace_kernel like every other launch.  Two dedicated kernels were built, tested bit-exact and measured in round 3, and
+// both were dropped: (1) a streaming pool — resident waves pull pixels from a device counter, a free lane starts
+// the next pixel from its PRIMARY ray in the same closest_hit calls as the others' bounce rays: every step then pays ray
+// generation, running mean, tone map and two scattered stores for a handful of lanes; Scene1 1080p 0.325 ms vs 0.286 ms,
+// Scene_indirect 0.81 vs 0.60; (2) a 256-pixel pool — four primary rounds per wave, 28-byte records in LDS, the pool over the
+// records, one dense fold/store pass: Scene1 0.293 vs 0.289 ms, Scene_indirect 0.73 vs 0.61, config 4's scene 0.73 vs 0.56.
+// A 1080p frame is 8 pixels per lane of the chip: whatever a wave saves by not thinning out it loses to the coarser grain of
+// the launch (a wave's second strip of 256 pixels is the whole launch's tail) and to the records' round trip.
 
 // Second half of a sample-chunked launch: one wave per tile, lane k folds slot k's colours, in sample
 // order, into the running mean and stores the pixel — the very operations the owner lanes of
@@ -1728,10 +1595,12 @@ __global__ void __launch_bounds__(64) pick_kernel(const KernelParams P, int px, 
 // learned order).  Any order gives the same image.
 constexpr int ORDER_BUCKETS = 16, ORDER_SORT_THREADS = 512;
 // Balance cost (srt_estimate_row_costs): TIME a block's pixels will take per sample, in 1/64 of the time of one analytic bounce
-// ray that meets no cluster.  Weights fitted by least squares on measured band times of configs 3 and 5 (tools/band_fit.py,
-// DESIGN.md §5): a sample of a pixel that traces nothing (the running mean is still evaluated sample by sample), a bounce ray,
-// every cluster whose spheres are tested exactly for it, a ray that goes through the mesh traversal, one that ends on a mesh.
-constexpr unsigned BAL_W_PIXEL = 7u, BAL_W_RAY = 64u, BAL_W_CAND = 0u, BAL_W_MESH_GO = 0u, BAL_W_MESH_HIT = 320u;
+// ray that meets no cluster.  Weights fitted by least squares on measured band times of configs 3 and 5 — the 135- / 270-row
+// bands an 8-rank run launches, equal split and shifted by half a band (tools/band_fit.py): a sample of a pixel
+// that traces nothing (the running mean is still evaluated sample by sample), a bounce ray, every cluster whose spheres are
+// tested exactly for it, a ray that goes through the mesh traversal (about ten analytic rays).  Whether a ray ENDS on a mesh
+// adds nothing once the traversal is counted (fitted weight 0).
+constexpr unsigned BAL_W_PIXEL = 2u, BAL_W_RAY = 64u, BAL_W_CAND = 11u, BAL_W_MESH_GO = 820u, BAL_W_MESH_HIT = 0u;
 template <bool SCENE_LDS>
 __global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, uint32_t* cost, int blocks_x, int n_blocks, uint32_t* balance_cost, uint32_t* features) {
     extern __shared__ float4 lds_scene[];

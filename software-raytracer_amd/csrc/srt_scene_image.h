@@ -3,6 +3,12 @@
 // ObjectsToRender (Raytracer.cpp:61) arrives as srt_object[] in list order.  The image is an
 // array of float4 that the kernel copies verbatim into LDS:
 //
+//   SRT_CONST_ROWS rows of constants come FIRST (the kernel's primitive offsets below count from behind them):
+//     rows 0..31   srt_powf's table, row i = the bytes of the doubles (invc_i, lnc_i) — read from LDS instead of from
+//                  constant memory (two dependent memory round trips per environment colour otherwise)
+//     rows 32..35  the environment (Raytracer.cpp:55-59), colours clamped like Color's constructor (Common.hpp:253-262):
+//                  (sky.rgb, sun.r) (horizon.rgb, sun.g) (ground.rgb, sun.b) (sunDirection.xyz, 0) — patched in place by
+//                  srt_set_environment, out of the kernel's argument registers
 //   [0, nu4)                 "uniform" spheres (cx,cy,cz,r*r), list order, padded to a
 //                            multiple of 4 with never-hit dummies (0,0,0,-1).  Every lane
 //                            tests all of them (wave-uniform broadcast reads).
@@ -49,9 +55,12 @@
 #include <algorithm>
 #include <vector>
 
+#include "srt_defs.h"
 #include "srt_pathtrace.h"
 
 namespace srt {
+
+constexpr int SRT_CONST_ROWS = 36, SRT_CONST_ENV_ROW = 32;
 
 struct SceneLayout {
     int nu4 = 0;      // uniform sphere slots (multiple of 4)
@@ -64,8 +73,16 @@ struct SceneLayout {
     int off_bounds = 0, off_box = 0, off_mat = 0;
     int total_vec4 = 0;
     int n_spheres = 0;  // real spheres (for statistics)
-    float cluster_c1max = 0.0f;  // max over the cluster bounds of |Cx| + |Cy| + |Cz|, rounded up
 };
+
+// the four environment rows of the constants block (colours through Color's clamping constructor, Common.hpp:253-262)
+inline void environment_rows(const srt_environment& e, float4 rows[4]) {
+    auto c0 = [](float v) { return v < 0 ? 0.0f : v; };
+    rows[0] = make_float4(c0(e.sky_color[0]), c0(e.sky_color[1]), c0(e.sky_color[2]), c0(e.sun_color[0]));
+    rows[1] = make_float4(c0(e.horizon_color[0]), c0(e.horizon_color[1]), c0(e.horizon_color[2]), c0(e.sun_color[1]));
+    rows[2] = make_float4(c0(e.ground_color[0]), c0(e.ground_color[1]), c0(e.ground_color[2]), c0(e.sun_color[2]));
+    rows[3] = make_float4(e.sun_direction[0], e.sun_direction[1], e.sun_direction[2], 0.0f);
+}
 
 inline uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) {  // 10 bits per axis
     auto spread = [](uint32_t v) {
@@ -191,9 +208,11 @@ inline SceneLayout build_scene_image(const srt_object* objects, size_t count, bo
     L.off_bounds = L.nsT;
     L.off_box = L.off_bounds + L.nc;
     L.off_mat = L.off_box + 2 * L.nb;
-    L.total_vec4 = L.off_mat + 3 * (L.nsT + L.nb + L.nm);
+    L.total_vec4 = SRT_CONST_ROWS + L.off_mat + 3 * (L.nsT + L.nb + L.nm);
 
-    img.assign((size_t)std::max(L.total_vec4, 1), make_float4(0, 0, 0, 0));
+    std::vector<float4> full((size_t)L.total_vec4, make_float4(0, 0, 0, 0));
+    memcpy(full.data(), srt_pow_table_host, 32 * sizeof(float4));  // 64 doubles = 32 rows; the environment rows are patched by the caller
+    img.assign((size_t)std::max(L.total_vec4 - SRT_CONST_ROWS, 1), make_float4(0, 0, 0, 0));
     const float4 dummy = make_float4(0, 0, 0, -1.0f);  // d2 > r*r always: never a candidate
     for (int p = 0; p < L.nsT; ++p) img[p] = dummy;
 
@@ -202,9 +221,11 @@ inline SceneLayout build_scene_image(const srt_object* objects, size_t count, bo
         float ord;
         int32_t idx = list_index;
         memcpy(&ord, &idx, 4);
-        img[L.off_mat + 3 * p + 0] = make_float4(m.smoothness, m.specular_amount, m.base_color[0], m.base_color[1]);
-        img[L.off_mat + 3 * p + 1] = make_float4(m.base_color[2], m.emissive_color[0], m.emissive_color[1], m.emissive_color[2]);
-        img[L.off_mat + 3 * p + 2] = make_float4(m.specular_color[0], m.specular_color[1], m.specular_color[2], ord);
+        // colours go through Color's clamping constructor (Common.hpp:253-262) HERE, once, instead of at every use in the kernel
+        auto c0 = [](float v) { return v < 0 ? 0.0f : v; };
+        img[L.off_mat + 3 * p + 0] = make_float4(m.smoothness, m.specular_amount, c0(m.base_color[0]), c0(m.base_color[1]));
+        img[L.off_mat + 3 * p + 1] = make_float4(c0(m.base_color[2]), c0(m.emissive_color[0]), c0(m.emissive_color[1]), c0(m.emissive_color[2]));
+        img[L.off_mat + 3 * p + 2] = make_float4(c0(m.specular_color[0]), c0(m.specular_color[1]), c0(m.specular_color[2]), ord);
     };
     auto put_sphere = [&](int p, int i) {
         const srt_object& o = objects[i];
@@ -257,10 +278,6 @@ inline SceneLayout build_scene_image(const srt_object* objects, size_t count, bo
         float Rgf = (float)Rg;
         if ((double)Rgf < Rg) Rgf = nextafterf(Rgf, INFINITY);
         img[L.off_bounds + c] = make_float4(Cf[0], Cf[1], Cf[2], Rgf);
-        const double c1 = (fabs((double)Cf[0]) + fabs((double)Cf[1]) + fabs((double)Cf[2])) * (1.0 + 1e-6);
-        float c1f = (float)c1;
-        if ((double)c1f < c1) c1f = nextafterf(c1f, INFINITY);
-        L.cluster_c1max = std::max(L.cluster_c1max, c1f);
     }
     for (size_t j = 0; j < boxes.size(); ++j) {
         const srt_object& o = objects[boxes[j]];
@@ -269,6 +286,8 @@ inline SceneLayout build_scene_image(const srt_object* objects, size_t count, bo
         put_material(L.nsT + (int)j, boxes[j]);
     }
     for (size_t m = 0; m < meshobjs.size(); ++m) put_material(L.nsT + L.nb + (int)m, meshobjs[m]);
+    memcpy(full.data() + SRT_CONST_ROWS, img.data(), (size_t)(L.total_vec4 - SRT_CONST_ROWS) * sizeof(float4));
+    img.swap(full);
     return L;
 }
 

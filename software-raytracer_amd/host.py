@@ -23,7 +23,7 @@ EXPORTS = [
     "srt_host_renderer_accumulation_frames", "srt_host_renderer_wait", "srt_host_renderer_read_framebuffer",
     "srt_host_renderer_read_accumulator", "srt_host_renderer_stats", "srt_host_renderer_handle",
     "srt_host_multi_create", "srt_host_multi_destroy", "srt_host_multi_set_scene", "srt_host_multi_configure",
-    "srt_host_multi_render_samples", "srt_host_multi_read_framebuffer", "srt_host_multi_band", "srt_host_multi_stats", "srt_host_multi_balance",
+    "srt_host_multi_render_samples", "srt_host_multi_read_framebuffer", "srt_host_multi_band", "srt_host_multi_stats", "srt_host_multi_balance", "srt_host_multi_use_equal_bands",
 ]
 
 _lib = None
@@ -105,6 +105,7 @@ def load_library():
     L.srt_host_multi_band.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.srt_host_multi_stats.argtypes = [vp, C.POINTER(Stats), C.c_int]
     L.srt_host_multi_balance.argtypes = [vp]
+    L.srt_host_multi_use_equal_bands.argtypes = [vp, C.c_int]
     L.srt_host_renderer_handle.restype = vp
     _lib = L
     return L
@@ -336,6 +337,11 @@ class MultiRenderer:
     def balance_bands(self):
         """Bands of equal estimated cost (srt_estimate_row_costs) instead of equal height."""
         self._ck(self.L.srt_host_multi_balance(self._h))
+
+    def use_equal_bands(self, equal=True):
+        """north_star's literal equal bands instead of the default split (bands of equal estimated cost, made at the first
+        render_samples after the scene / camera / settings change)."""
+        self._ck(self.L.srt_host_multi_use_equal_bands(self._h, 1 if equal else 0))
 
     def band(self, i):
         b, e = C.c_int(), C.c_int()

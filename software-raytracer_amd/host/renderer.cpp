@@ -147,17 +147,11 @@ std::vector<float> PathTraceRenderer::ReadAccumulator() {
 // ---- MultiGpuRenderer -------------------------------------------------------------------
 MultiGpuRenderer::MultiGpuRenderer(const std::vector<int>& devices, int width, int height) : width_(width), height_(height) {
     if (devices.empty() || (int)devices.size() > height) throw RendererError(SRT_ERR_INVALID_ARG, "MultiGpuRenderer: need 1 <= devices <= height");
-    {
-        const int n = (int)devices.size(), q = height / n, r = height % n;
-        for (int k = 0; k <= n; ++k) bounds_.push_back(k * q + (k < r ? k : r));
-    }
+    bounds_.assign(devices.size() + 1, 0);
     try {
         for (int d : devices) parts_.push_back(new PathTraceRenderer(d, width, height));
-        for (size_t i = 0; i < parts_.size(); ++i) {
-            int b, e;
-            Band(i, &b, &e);
-            parts_[i]->SetRowBand(b, e);
-        }
+        EqualBands();
+        split_pending_ = true;  // (the first RenderSamples makes the default split)
     } catch (...) {
         for (PathTraceRenderer* p : parts_) delete p;
         throw;
@@ -171,6 +165,18 @@ MultiGpuRenderer::~MultiGpuRenderer() {
 void MultiGpuRenderer::Band(size_t i, int* begin, int* end) const {
     *begin = bounds_[i];
     *end = bounds_[i + 1];
+}
+
+void MultiGpuRenderer::EqualBands() {
+    const int n = (int)parts_.size(), q = height_ / n, r = height_ % n;
+    for (int k = 0; k <= n; ++k) bounds_[(size_t)k] = k * q + (k < r ? k : r);
+    for (int k = 0; k < n; ++k) parts_[(size_t)k]->SetRowBand(bounds_[(size_t)k], bounds_[(size_t)k + 1]);
+    split_pending_ = false;
+}
+
+void MultiGpuRenderer::UseEqualBands(bool equal) {
+    equal_bands_ = equal;
+    Invalidate();  // rows change owners: every band starts over
 }
 
 void MultiGpuRenderer::BalanceBands() {
@@ -189,20 +195,22 @@ void MultiGpuRenderer::BalanceBands() {
     for (int i = 0; i < height_; ++i) prefix[(size_t)i + 1] = prefix[(size_t)i] + (cost[(size_t)i] > 0 ? cost[(size_t)i] : 0.0);
     const double total = prefix[(size_t)height_];
     bounds_[0] = 0;
-    for (int k = 1; k < n; ++k) {  // first row whose prefix cost reaches k/n of the total, rounded to 8 rows, every band >= 1 row
+    for (int k = 1; k < n; ++k) {  // first row whose prefix cost reaches k/n of the total, rounded to 16 rows (whole blocks of tiles), every band >= 1 row
         const int lo = bounds_[(size_t)k - 1] + 1, hi = height_ - (n - k);
         int i = lo;
         while (i < hi && prefix[(size_t)i] < total * k / n) ++i;
-        const int j = ((i + 4) / 8) * 8;
+        const int j = ((i + 8) / 16) * 16;
         if (j >= lo && j <= hi) i = j;
         bounds_[(size_t)k] = i < lo ? lo : (i > hi ? hi : i);
     }
     bounds_[(size_t)n] = height_;
     for (int k = 0; k < n; ++k) parts_[(size_t)k]->SetRowBand(bounds_[(size_t)k], bounds_[(size_t)k + 1]);
+    split_pending_ = false;
 }
 
 void MultiGpuRenderer::SetScene(const Scene& scene) {
     for (PathTraceRenderer* p : parts_) p->SetScene(scene);
+    split_pending_ = true;
 }
 
 void MultiGpuRenderer::SetEnvironment(const srt_environment& env) {
@@ -217,13 +225,20 @@ void MultiGpuRenderer::Configure(const Transform& camera, int fov, int max_bounc
         p->seed = seed;
         p->Invalidate();
     }
+    split_pending_ = true;
 }
 
 void MultiGpuRenderer::Invalidate() {
     for (PathTraceRenderer* p : parts_) p->Invalidate();
+    split_pending_ = true;
 }
 
 void MultiGpuRenderer::RenderSamples(uint32_t count, bool count_rays) {
+    if (split_pending_) {  // the accumulation starts over: the moment rows may change owners
+        if (equal_bands_) EqualBands();
+        else BalanceBands();
+        split_pending_ = false;
+    }
     for (PathTraceRenderer* p : parts_) p->RenderSamples(count, count_rays);  // asynchronous: one stream per part
     for (size_t i = 1; i < parts_.size(); ++i) {                              // the one gather
         int b, e;

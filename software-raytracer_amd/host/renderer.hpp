@@ -138,13 +138,17 @@ class MultiGpuRenderer {
 
     size_t size() const { return parts_.size(); }
     PathTraceRenderer& part(size_t i) { return *parts_[i]; }
-    // memory-row band of part i: equal bands (the first height % N parts take one more row) until
-    // BalanceBands() has been called
+    // memory-row band of part i.  Equal bands (the first height % N parts take one more row) until the first
+    // RenderSamples; from then on, by default, bands of equal ESTIMATED cost (below).
     void Band(size_t i, int* begin, int* end) const;
     // Bands of equal ESTIMATED cost for the current scene, camera and bounce count (srt_estimate_row_costs on part 0:
-    // a device-side probe, ~0.1 ms), boundaries on multiples of 8 rows.  Equal bands leave the GPUs that own sky idle:
-    // on Scene1 the slowest of 8 equal bands takes 2.6x the average.  Call after SetScene / Configure.
+    // a device-side probe, ~0.1 ms), boundaries on multiples of 16 rows (whole blocks of tiles).  Equal bands leave the GPUs
+    // that own sky idle: on Scene1 the slowest of 8 equal bands takes 2.2x the average.  This is the DEFAULT
+    // split: RenderSamples applies it whenever the accumulation (re)starts — after SetScene, Configure or Invalidate, when every
+    // band starts from sample 1 anyway — so a caller never has to ask.  UseEqualBands(true) goes back to north_star's literal
+    // equal bands; BalanceBands() itself stays callable.
     void BalanceBands();
+    void UseEqualBands(bool equal);
 
     void SetScene(const Scene& scene);  // replicated: every device gets its own copy (a few KB; meshes: a few MB)
     void SetEnvironment(const srt_environment& env);
@@ -163,6 +167,9 @@ class MultiGpuRenderer {
     std::vector<PathTraceRenderer*> parts_;
     std::vector<int> bounds_;  // band i = memory rows [bounds_[i], bounds_[i + 1])
     int width_, height_;
+    bool equal_bands_ = false;    // UseEqualBands(true)
+    bool split_pending_ = true;   // the accumulation restarts with the next RenderSamples: (re)make the split then
+    void EqualBands();
 };
 
 }  // namespace srt_host

@@ -17,7 +17,8 @@ static void usage() {
                  "usage: srt_render --scene FILE [--width 1280] [--height 720] [--spp 32] [--bounces 2]\n"
                  "                  [--fov 55] [--seed 0] [--device 0 | --devices 0,1,2,...] [--out frame.ppm] [--resave FILE]\n"
                  "  --devices: one frame over several GPUs of this node in one process (equal row bands, one gather;\n"
-                 "             a device may be listed more than once); --balance: bands of equal estimated cost instead of equal height\n");
+                 "             a device may be listed more than once); bands of equal estimated cost (default; --balance is accepted\n"
+                 "             and means the same), --equal-bands: bands of equal height\n");
 }
 
 int main(int argc, char** argv) {
@@ -25,7 +26,7 @@ int main(int argc, char** argv) {
     int W = 1280, H = 720, spp = 32, bounces = 2, fov = 55, device = 0;  // Raytracer.cpp:26-27,31-32
     unsigned seed = 0;
     std::vector<int> devices;
-    bool balance = false;
+    bool equal_bands = false;
     for (int i = 1; i < argc; ++i) {
         auto need = [&](const char* n) -> const char* {
             if (i + 1 >= argc) {
@@ -42,7 +43,8 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--fov")) fov = std::atoi(need("--fov"));
         else if (!std::strcmp(argv[i], "--seed")) seed = (unsigned)std::strtoul(need("--seed"), nullptr, 10);
         else if (!std::strcmp(argv[i], "--device")) device = std::atoi(need("--device"));
-        else if (!std::strcmp(argv[i], "--balance")) balance = true;
+        else if (!std::strcmp(argv[i], "--balance")) equal_bands = false;
+        else if (!std::strcmp(argv[i], "--equal-bands")) equal_bands = true;
         else if (!std::strcmp(argv[i], "--devices")) {
             for (const char* p = need("--devices"); *p;) {
                 devices.push_back(std::atoi(p));
@@ -85,7 +87,7 @@ int main(int argc, char** argv) {
             MultiGpuRenderer m(devices, W, H);
             m.SetScene(scene);
             m.Configure(Transform(), fov, bounces, seed);
-            if (balance) m.BalanceBands();
+            if (equal_bands) m.UseEqualBands(true);
             auto t0 = std::chrono::steady_clock::now();
             m.RenderSamples((uint32_t)spp, true);
             std::vector<uint32_t> fb((size_t)W * H);

@@ -24,6 +24,12 @@ WORK = {  # name: scene, mesh, width, height, spp, bounces, memory rows (None = 
     "c3r4": ("Scene1", 0, 1920, 1080, 512, 8, (540, 675)),
     "c3r7": ("Scene1", 0, 1920, 1080, 512, 8, (945, 1080)),
     "c5r4": ("Scene1", 224, 3840, 2160, 1024, 16, (1080, 1350)),
+    "c3n72": ("Scene1", 0, 1920, 1080, 512, 8, (744, 816)),    # narrow bands of a cost-balanced 8-rank split of config 3
+    "c3n64": ("Scene1", 0, 1920, 1080, 512, 8, (816, 880)),
+    "c3n48": ("Scene1", 0, 1920, 1080, 512, 8, (936, 984)),
+    "c3t400": ("Scene1", 0, 1920, 1080, 512, 8, (0, 400)),
+    "c5n112": ("Scene1", 224, 3840, 2160, 1024, 16, (1592, 1704)),
+    "c5n128": ("Scene1", 224, 3840, 2160, 1024, 16, (1360, 1488)),
     "1spp": ("Scene1", 0, 1920, 1080, 1, 8, None),
     "1spp_ind": ("Scene_indirect", 0, 1920, 1080, 1, 8, None),
     "1spp_c4": ("Scene1", 224, 1920, 1080, 1, 8, None),

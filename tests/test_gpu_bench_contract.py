@@ -51,4 +51,4 @@ def test_two_rank_rehearsal(balance, port):
     if balance == "equal":
         assert bands[0][1] == 180 and "calibration_launches" not in d["config"]
     else:
-        assert bands[0][1] > 180 and d["config"]["calibration_launches"] == 1  # Scene1: sky on top, the upper band is taller
+        assert bands[0][1] > 180 and d["config"]["calibration_launches"] == 0 and d["config"]["probe_launches"] == 1  # Scene1: sky on top, the upper band is taller

@@ -1,6 +1,6 @@
 """The native (C++ / C-ABI, no Python in the data path) multi-GPU row-stripe renderer of SURVEY §8e:
-host/renderer.hpp MultiGpuRenderer = one srt_context and stream per device, equal memory-row bands, joined by
-srt_gather_band (device-to-device copies into the first device's framebuffer).  On a one-GPU box the N contexts
+host/renderer.hpp MultiGpuRenderer = one srt_context and stream per device, memory-row bands (of equal estimated cost by default,
+of equal height on request), joined by srt_gather_band (device-to-device copies into the first device's framebuffer).  On a one-GPU box the N contexts
 all live on device 0 — the control flow, the band arithmetic and the stream ordering are the same."""
 import ctypes as C
 import subprocess
@@ -14,16 +14,22 @@ from conftest import ROOT, scene_path
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("equal", [True, False])
 @pytest.mark.parametrize("name,n_parts,w,h,spp", [("Scene_indirect", 3, 200, 113, 3), ("Scene1", 8, 1920, 1080, 4), ("Scene3", 5, 333, 97, 20)])
-def test_multi_renderer_equals_single_device_and_oracle(srt, oracle, name, n_parts, w, h, spp):
+def test_multi_renderer_equals_single_device_and_oracle(srt, oracle, name, n_parts, w, h, spp, equal):
     scene = srt.host.Scene(scene_path(name))
     m = srt.host.MultiRenderer([0] * n_parts, w, h)
     m.set_scene(scene)
     m.configure(fov=55, max_bounces=6, seed=3)
+    if equal:
+        m.use_equal_bands()
+    m.render_samples(spp, count_rays=True)
     bands = [m.band(i) for i in range(n_parts)]
     assert bands[0][0] == 0 and bands[-1][1] == h and all(bands[i][1] == bands[i + 1][0] for i in range(n_parts - 1))
-    assert max(b - a for a, b in bands) - min(b - a for a, b in bands) <= 1  # equal bands (first h % N one row taller)
-    m.render_samples(spp, count_rays=True)
+    if equal:
+        assert max(b - a for a, b in bands) - min(b - a for a, b in bands) <= 1  # equal bands (first h % N one row taller)
+    elif name == "Scene1":
+        assert bands[0][1] - bands[0][0] > 2 * (bands[-1][1] - bands[-1][0])  # the default split: the sky band is far taller than the floor band
     fb = m.framebuffer()
     st = m.stats()
     assert sum(s.path_samples for s in st) == w * h * spp
@@ -63,13 +69,17 @@ def test_balanced_bands_equal_the_single_device_frame(srt):
     m = srt.host.MultiRenderer([0] * n_parts, w, h)
     m.set_scene(scene)
     m.configure(fov=55, max_bounces=8, seed=0)
-    equal = [m.band(i) for i in range(n_parts)]
+    equal = [m.band(i) for i in range(n_parts)]  # (before the first render: the constructor's equal bands)
     m.balance_bands()
     bands = [m.band(i) for i in range(n_parts)]
     assert bands != equal and bands[0][0] == 0 and bands[-1][1] == h and all(bands[i][1] == bands[i + 1][0] for i in range(n_parts - 1))
     assert bands[0][1] - bands[0][0] > bands[-1][1] - bands[-1][0]  # the sky band is the tallest
     m.render_samples(4)
     assert np.array_equal(m.framebuffer(), pt.framebuffer())
+    assert [m.band(i) for i in range(n_parts)] == bands  # the default split of render_samples IS balance_bands(): deterministic
+    m.use_equal_bands()
+    m.render_samples(4)
+    assert [m.band(i) for i in range(n_parts)] == equal and np.array_equal(m.framebuffer(), pt.framebuffer())
     m.close()
     pt.close()
 

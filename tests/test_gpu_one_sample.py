@@ -1,6 +1,8 @@
-"""One-sample launches — the reference's own frame loop adds ONE sample per frame (Raytracer.cpp:572-595) — run the
-streaming kernel (pathtrace_one_kernel: resident waves pull 32 x 8 pixel chunks, a free lane starts the next pixel's path from
-its primary ray).  Bit-exact against the oracle like every other launch shape: framebuffer, accumulator, ray count."""
+"""One-sample launches — the reference's own frame loop adds ONE sample per frame (Raytracer.cpp:572-595).  They run through
+pathtrace_kernel like every other launch shape (two dedicated one-sample kernels were built and dropped in round 3, DESIGN.md
+§4.9; these tests were written for them and stay as the coverage of the frame loop's launch shape): odd sizes, 0 bounces, the
+sample-by-sample frame loop against one multi-sample launch, row bands onto an accumulated frame, meshes, a scene image beyond
+LDS.  Bit-exact against the oracle: framebuffer, accumulator, ray count."""
 import ctypes as C
 
 import numpy as np
@@ -31,7 +33,7 @@ def _same(pt, ofb, oacc, rows=None):
 @pytest.mark.parametrize("name", SCENE_NAMES)
 @pytest.mark.parametrize("w,h,bounces", [(320, 180, 8), (131, 77, 3), (33, 9, 16), (640, 40, 0)])
 def test_one_sample_frame_bit_exact(srt, oracle, name, w, h, bounces):
-    """odd sizes: chunks cut at the right edge and at the band's last rows; 0 bounces: the emissive colour only"""
+    """odd sizes: tiles cut at the right edge and at the band's last rows; 0 bounces: the emissive colour only"""
     pt, oarr, n = _setup(srt, oracle, name, w, h)
     pt.render(spp=1, bounces=bounces, seed=3, count_rays=True)
     ofb, oacc, orays = oracle.render(oarr, n, oracle.default_environment(), oracle.default_camera(), w, h, spp=1, bounces=bounces, seed=3)
@@ -87,8 +89,7 @@ def test_one_sample_row_bands_and_resume(srt, oracle):
 
 
 def test_one_sample_with_mesh(srt, oracle):
-    """EXTENSION: the mesh instantiation of the streaming kernel (primary and bounce rays share the mesh phases; rays that wait
-    for a phase are parked while the wave takes new pixels)"""
+    """EXTENSION: one-sample launches of a mesh scene (rays that wait for a mesh phase are parked)"""
     objs = oracle.load_scene_json_py(scene_path("Scene1"))
     big = objs[64]
     objs[64] = dict(type=oracle.OBJ_MESH, position=big["position"], mesh=0, base=big["base"], emissive=big["emissive"],
@@ -113,7 +114,7 @@ def test_one_sample_with_mesh(srt, oracle):
 
 
 def test_one_sample_scene_beyond_lds(srt, oracle):
-    """a scene image that does not fit into LDS: the streaming kernel's HBM-scene instantiation"""
+    """a scene image that does not fit into LDS (the HBM-scene instantiation)"""
     rng = np.random.default_rng(5)
     objs = [dict(type=oracle.OBJ_SPHERE, position=(0, -1001, 5), radius=1000, base=(.8, .8, .8))]
     for _ in range(3400):

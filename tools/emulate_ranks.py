@@ -1,21 +1,62 @@
 #!/usr/bin/env python3
-"""Every rank's launch of an N-rank run, one after the other on ONE GPU (DESIGN.md §5's table).
-usage (on the GPU box): python3 tools/emulate_ranks.py <config> <N> <equal|probe> [--steps K]
-Prints one line per rank (rows, kernel ms) and the slowest; kernel times only, no gather."""
-import json, os, subprocess, sys
+"""Every rank's launch of an N-rank run, one after the other on ONE GPU, in one process (DESIGN.md §5's table).
+usage (on the GPU box): python3 tools/emulate_ranks.py <config 3|5> [--ranks 2,4,8] [--modes probe,equal] [--json out.json]
+For every N and split: each band is rendered by a context of its own (as a rank would: its own dispatch order, its own sample
+chunking), 3 warm-up launches, then the median kernel time of 5.  Prints per-rank ms, mean / slowest, and the whole frame on one
+GPU / N / slowest.  Kernel times only — no gather (<= 4.15 MB per rank)."""
+import argparse, importlib, json, os, statistics, sys, tempfile
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument("config", type=int, choices=[3, 5])
+ap.add_argument("--ranks", default="2,4,8")
+ap.add_argument("--modes", default="probe,equal")
+ap.add_argument("--json", default="")
+a = ap.parse_args()
+CFG = {3: ("Scene1", 0, 1920, 1080, 512, 8), 5: ("Scene1", 224, 3840, 2160, 1024, 16)}
+scene, mesh, W, H, spp, bounces = CFG[a.config]
+srt = importlib.import_module("software-raytracer_amd")
+stripes = importlib.import_module("software-raytracer_amd.stripes")
+path = os.path.join(ROOT, "software-raytracer_amd", "scenes", scene + ".json")
+if mesh:
+    sj = json.load(open(path))
+    sj["SceneObjects"][64]["Renderer"] = {"Type": "Mesh", "Primitive": "UVSphere", "Radius": 1.0, "Stacks": mesh, "Slices": mesh}
+    tmp = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False); json.dump(sj, tmp); tmp.close(); path = tmp.name
+sc = srt.host.Scene(path)
+if mesh:
+    os.unlink(path)
+objs, n = sc.objects_copy(); meshes, nm = sc.meshes()
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cfg, n, mode = sys.argv[1], int(sys.argv[2]), sys.argv[3]
-steps = sys.argv[5] if len(sys.argv) > 5 and sys.argv[4] == "--steps" else "5"
-ms = []
-for k in range(n):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--rank", "%d/%d" % (k, n), "--balance", mode, "--steps", steps, "--warmup", "2",
-                        "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    js = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    if not js:
-        print("rank %d failed: %s" % (k, r.stderr[-300:]), flush=True)
-        sys.exit(1)
-    d = json.loads(js[-1])
-    ms.append(d["roofline"]["kernel_ms"])
-    print("config %s N=%d %s rank %d rows %s: %.2f ms" % (cfg, n, mode, k, d["per_rank"][0]["rows"], ms[-1]), flush=True)
-print("config %s N=%d %s: %s | slowest %.2f, mean %.2f, mean / slowest %.2f" % (cfg, n, mode, " / ".join("%.1f" % v for v in ms), max(ms), sum(ms) / n, sum(ms) / n / max(ms)), flush=True)
+
+def tracer():
+    pt = srt.PathTracer(W, H)
+    pt.set_meshes(meshes, nm); pt.set_scene(objs, n); pt.set_camera(srt.default_camera())
+    return pt
+
+
+def band_ms(rows):
+    pt = tracer()
+    ts = []
+    for i in range(8):
+        pt.render(spp=spp, bounces=bounces, seed=0, rows=rows)
+        ts.append(pt.stats().kernel_ms)
+    pt.close()
+    return statistics.median(ts[3:])
+
+
+pt = tracer()
+row_cost = pt.estimate_row_costs(bounces, 0)
+pt.close()
+whole = band_ms((0, H))
+print("config %d: whole frame on one GPU %.2f ms" % (a.config, whole), flush=True)
+doc = {"config": a.config, "whole_frame_ms": whole, "splits": []}
+for N in (int(v) for v in a.ranks.split(",")):
+    for mode in a.modes.split(","):
+        bands = stripes.partition_rows(H, N, row_cost if mode == "probe" else None, align=16 if mode == "probe" else 1)
+        ms = [band_ms(b) for b in bands]
+        eff = sum(ms) / N / max(ms)
+        print("config %d N=%d %-5s rows %s\n      ms %s | slowest %.2f  mean/slowest %.3f  (whole/N)/slowest %.3f" %
+              (a.config, N, mode, [b[0] for b in bands] + [H], " / ".join("%.2f" % v for v in ms), max(ms), eff, whole / N / max(ms)), flush=True)
+        doc["splits"].append({"ranks": N, "split": mode, "bands": [list(b) for b in bands], "kernel_ms": ms, "mean_over_slowest": eff, "whole_over_n_over_slowest": whole / N / max(ms)})
+if a.json:
+    json.dump(doc, open(a.json, "w"), indent=1)
