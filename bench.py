@@ -224,7 +224,7 @@ def main():
     if n_parts > 1 and args.balance == "probe":
         t_cal = time.perf_counter()
         row_cost = pt.estimate_row_costs(bounces, SEED)
-        bands = stripes.partition_rows(H, n_parts, row_cost, align=16)  # whole blocks of tiles
+        bands = stripes.partition_rows(H, n_parts, row_cost, align=8)
         calibration = {"calibration_launches": 0, "probe_launches": 1, "calibration_ms": (time.perf_counter() - t_cal) * 1e3,
                        "calibration": "none: srt_estimate_row_costs is one device-side probe of 1/16 of the pixels at one sample (no launch of the workload), same numbers on every rank"}
         rb, re = bands[share[0] if share else rank]
@@ -481,6 +481,14 @@ def main():
         }
         if calibration:
             out["config"].update(calibration)
+        if world > 1 or share:
+            # what every rank's launch of this split took when the ranks were run one after the other on ONE GPU (kernel times
+            # only, no gather; tools/emulate_ranks.py, committed as profiles/emulated_ranks.json) — both splits, so that the
+            # line of an N-GPU run can be read against it.  No scaling curve has been measured on more than one GPU.
+            emu = load_json(os.path.join(ROOT, "profiles", "emulated_ranks.json")).get("config %d" % cfg_id, {})
+            n_key = str(share[1] if share else world)
+            if emu.get(n_key):
+                out["config"]["emulated_on_one_gpu"] = dict(emu[n_key], note=emu.get("note"))
         if world > 1:
             out["stripe_parity_vs_single_device"] = stripe_parity
             if stripe_parity is False:

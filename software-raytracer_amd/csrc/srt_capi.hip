@@ -324,7 +324,7 @@ static int set_scene_impl(srt_context* ctx, const srt_object* objects, size_t co
         // instantiation, same bits); the pick kernel runs one wave, so it is judged separately
         const size_t image_bytes = (size_t)L.total_vec4 * sizeof(float4);
         const size_t mesh_scratch = has_mesh ? (size_t)(srt::WG_MESH_SCRATCH_BYTES) : 0;
-        ctx->scene_in_lds[v] = image_bytes + srt::WG_SCRATCH_BYTES + mesh_scratch <= (size_t)ctx->lds_limit_bytes;
+        ctx->scene_in_lds[v] = image_bytes + (has_mesh ? (size_t)srt::WG_SCRATCH_BYTES : (size_t)srt::WG_SCRATCH_BYTES_ANALYTIC) + mesh_scratch <= (size_t)ctx->lds_limit_bytes;
         ctx->pick_in_lds[v] = image_bytes + srt::WAVE_SCRATCH_BYTES + srt::MESH_WAVE_BYTES <= (size_t)ctx->lds_limit_bytes;
         if (ctx->h_scene[v].size() > ctx->scene_capacity_vec4[v] || !ctx->d_scene[v]) {
             if (ctx->d_scene[v]) SRT_HIP(ctx, hipFree(ctx->d_scene[v]));
@@ -539,8 +539,8 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
     K.framebuffer = ctx->d_fb;
     K.ray_counter = ctx->d_rays;
 
-    lds_bytes = (ctx->scene_in_lds[img] ? (size_t)(SL.total_vec4 > 0 ? SL.total_vec4 : 1) * sizeof(float4) : 0) + srt::WG_SCRATCH_BYTES +
-                (ctx->mesh_image.n_tris > 0 ? srt::WG_MESH_SCRATCH_BYTES : 0);
+    lds_bytes = (ctx->scene_in_lds[img] ? (size_t)(SL.total_vec4 > 0 ? SL.total_vec4 : 1) * sizeof(float4) : 0) +
+                (ctx->mesh_image.n_tris > 0 ? srt::WG_SCRATCH_BYTES + srt::WG_MESH_SCRATCH_BYTES : srt::WG_SCRATCH_BYTES_ANALYTIC);
     return SRT_OK;
 }
 
@@ -642,6 +642,10 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
 #endif
         }
         if (c > p->sample_count / 16) c = p->sample_count / 16;
+        // A mesh launch that the rule leaves in ONE piece keeps full 8 x 8 tiles: the small tiles chosen above for launches of few
+        // blocks (tuned in round 1 on analytic scenes at 16..63 spp) cost the mesh kernel more than they balance — config 5's
+        // floor bands of a cost-balanced 8-rank split (1024 spp, 128 / 208 rows): 107 -> 92 ms, 90 -> 78 ms (round 3).
+        if (c < 2 && defer_env <= 0 && K.n_tris > 0 && tile_env == 0) tile_h = srt::TILE_H;
         if (c >= 2 || defer_env > 0) {
             chunk = (int)((p->sample_count + c - 1) / c);
             if (defer_env > 0) chunk = defer_env;
@@ -817,14 +821,16 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
                srt::pathtrace_kernel<3, true, false, true, false>, srt::pathtrace_kernel<3, true, false, false, true>);
 #ifdef SRT_DEV  // occupancy variants for A/B timing; never in the shipped library
     else if (use == 1 && in_lds && !multi && !defer)
-        hipLaunchKernelGGL((srt::pathtrace_kernel<5, false>), grid, block, lds_bytes, ctx->stream, K);
+        hipLaunchKernelGGL((srt::pathtrace_kernel<4, false>), grid, block, lds_bytes, ctx->stream, K);
     else if (use == 3 && in_lds && !multi && !defer)
         hipLaunchKernelGGL((srt::pathtrace_kernel<3, false>), grid, block, lds_bytes, ctx->stream, K);
 #endif
     else
-        launch(srt::pathtrace_kernel<4, false, true, false, false>, srt::pathtrace_kernel<4, false, true, true, false>,
-               srt::pathtrace_kernel<4, false, true, false, true>, srt::pathtrace_kernel<4, false, false, false, false>,
-               srt::pathtrace_kernel<4, false, false, true, false>, srt::pathtrace_kernel<4, false, false, false, true>);
+        // (five waves per SIMD, 96 VGPRs: the full-tile and the sample-chunk instantiations fit without a spill; the multi-sample
+        // hand-out of small tiles / progressive blocks would spill 16 registers and stays at four)
+        launch(srt::pathtrace_kernel<5, false, true, false, false>, srt::pathtrace_kernel<4, false, true, true, false>,
+               srt::pathtrace_kernel<5, false, true, false, true>, srt::pathtrace_kernel<5, false, false, false, false>,
+               srt::pathtrace_kernel<4, false, false, true, false>, srt::pathtrace_kernel<5, false, false, false, true>);
     if (defer) {
         SRT_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(srt::fold_kernel, dim3((unsigned)wg8), dim3(256), 0, ctx->stream, K, (int)wg_x);

@@ -107,10 +107,16 @@ constexpr int WG_W = TILE_W * WG_TILES_X, WG_H = TILE_H * WG_TILES_Y;
 // per-wave LDS scratch behind the scene image: work list of (ray lane, cluster) items + one
 // 64-bit result slot per lane (balanced phase 2 of closest_hit)
 constexpr int WORK_MAX = 512;
-constexpr int RING_DEPTH = 4;  // ring entries per slot when all 64 pixels of the tile are traced (power of two)
+// ring entries per slot when all 64 pixels of the tile are traced (powers of two).  The mesh kernel (3 waves per SIMD, its LDS is
+// what holds it there) keeps 4.  The analytic kernel runs FIVE waves per SIMD since round 3 (96 VGPRs): five workgroups' LDS fit
+// into a CU's 160 KiB only with 2 entries per slot — with 4 waves per SIMD the shorter ring costs 3..7 %, the fifth wave wins
+// that back and more where paths are long: Scene_indirect -3.7 %, Scene3 -4.5 %, Scene1 / Scene1_reflection +-0.
+constexpr int RING_DEPTH = 4, RING_DEPTH_ANALYTIC = 2;
 // per-wave: 64 result slots (8 B) | work list (2 B) | 64 pixel records (48 B) | ring (16 B)
 constexpr int WAVE_SCRATCH_BYTES = 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4 + 64 * RING_DEPTH * 16;
+constexpr int WAVE_SCRATCH_BYTES_ANALYTIC = 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4 + 64 * RING_DEPTH_ANALYTIC * 16;
 constexpr int WG_SCRATCH_BYTES = WAVE_SCRATCH_BYTES * WG_TILES_X * WG_TILES_Y;
+constexpr int WG_SCRATCH_BYTES_ANALYTIC = WAVE_SCRATCH_BYTES_ANALYTIC * WG_TILES_X * WG_TILES_Y;
 // extra per-wave LDS of the mesh kernel: node LIFO + leaf queue of the cooperative BVH traversal
 // (sized so that three workgroups of the mesh kernel still fit into a CU's 160 KiB next to the Scene1-sized image)
 constexpr int MESH_QN = 448, MESH_QL = 320;
@@ -169,28 +175,13 @@ __device__ __forceinline__ float rand_unit(uint32_t r) {
     return __builtin_fmaf(__builtin_fmaf(-q0, b, a), y, q0);
 }
 
-// sqrtf, correctly rounded (Object.hpp:131, Common.hpp:159): v_sqrt_f32 is good to one ulp; the two neighbours' residuals
-// x - s' * s (exact in an FMA) say which of the three is the rounded root — the very sequence hipcc emits for sqrtf, minus its
-// rescaling of tiny arguments and its pass-through of 0 / inf, neither of which the sequence needs: for +-0, +inf and NaN the
-// residual tests come out false and v_sqrt_f32's own result stands.  Arguments in (0, 2^-96), where v_sqrt_f32's accuracy is
-// not specified, take hipcc's general sqrtf (one wave-uniform branch, in practice never taken).  11 instructions instead of 20.
-__device__ __forceinline__ float sqrt_rn(float x) {
-    if (__builtin_amdgcn_ballot_w64(__float_as_uint(x) - 1u < 0x0F800000u - 1u) != 0ull) return sqrtf(x);  // some lane: 0 < x < 2^-96
-    float s = __builtin_amdgcn_sqrtf(x);
-    const float s_dn = __int_as_float(__float_as_int(s) - 1), s_up = __int_as_float(__float_as_int(s) + 1);
-    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
-    s = r_dn <= 0.0f ? s_dn : s;
-    s = r_up > 0.0f ? s_up : s;
-    return s;
-}
-
 struct V3 {
     float x, y, z;
 };
 __device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
 // float3::Normalized (Common.hpp:159-162)
 __device__ __forceinline__ V3 normalized(V3 a) {
-    float length = sqrt_rn((a.x * a.x + a.y * a.y) + a.z * a.z);
+    float length = sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z);
     return v3(a.x / length, a.y / length, a.z / length);
 }
 __device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
@@ -320,7 +311,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
     };
     auto part2 = [&](const Cand& k, int p, float& tb, int& pb) {
         if (__builtin_amdgcn_ballot_w64(k.c) != 0ull) {
-            float t1 = k.tc - sqrt_rn(k.x);  // :131-133
+            float t1 = k.tc - sqrtf(k.x);  // :131-133
             // Raytracer.cpp:130-132; on an exact tie the earlier entry of ObjectsToRender wins.
             // Branch-free on purpose (see the note in the triangle phase).
             const bool tie = k.c & (t1 == tb) & (pb >= 0);
@@ -391,9 +382,12 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             const int total = __builtin_amdgcn_readlane((int)incl, 63);
             SRT_TICK(4);
 #if defined(SRT_STATS) && SRT_STATS == 4
-            SRT_STAT(2, total);
-            SRT_STAT(3, (total + 63) / 64);
-            SRT_STAT(7, __builtin_popcountll(__builtin_amdgcn_ballot_w64(active)));
+            {
+                const int st_active = __builtin_popcountll(__builtin_amdgcn_ballot_w64(active));
+                SRT_STAT(2, total);
+                SRT_STAT(3, (total + 63) / 64);
+                SRT_STAT(7, st_active);
+            }
 #endif
             if (total > 0 && total <= WORK_MAX) {
                 const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -955,10 +949,11 @@ __device__ __forceinline__ void store_pixel(const KernelParams& P, uint32_t pix,
 // [waves x MESH_WAVE_BYTES (mesh kernel only)].  SCENE_LDS == false is the fallback for scene images
 // that do not fit next to the scratch (thousands of analytic primitives): the same image is then read
 // from HBM/L2 through the same accessors — slower per test, same arithmetic, same bits.
-template <bool SCENE_LDS>
+template <bool SCENE_LDS, bool MESH_LAYOUT = true>
 __device__ __forceinline__ Lds make_lds(const KernelParams& P, float4* lds, int waves, int wave) {
+    constexpr int stride = MESH_LAYOUT ? WAVE_SCRATCH_BYTES : WAVE_SCRATCH_BYTES_ANALYTIC;  // (the analytic pool kernel's ring is shorter)
     char* wg = reinterpret_cast<char*>(lds + (SCENE_LDS ? P.scene_vec4 : 0));
-    char* scratch = wg + wave * WAVE_SCRATCH_BYTES;
+    char* scratch = wg + wave * stride;
     const float4* image;
     if constexpr (SCENE_LDS)
         image = lds;
@@ -968,7 +963,7 @@ __device__ __forceinline__ Lds make_lds(const KernelParams& P, float4* lds, int 
                reinterpret_cast<unsigned long long*>(scratch), reinterpret_cast<unsigned short*>(scratch + 64 * 8),
                reinterpret_cast<float*>(scratch + 64 * 8 + WORK_MAX * 2),
                reinterpret_cast<float4*>(scratch + 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4),
-               reinterpret_cast<unsigned*>(wg + waves * WAVE_SCRATCH_BYTES + wave * MESH_WAVE_BYTES)};
+               reinterpret_cast<unsigned*>(wg + waves * stride + wave * MESH_WAVE_BYTES)};
 }
 
 // MULTI: the path pool may hand several samples of one pixel out at once (used with small tiles, where
@@ -990,7 +985,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         for (int i = threadIdx.x; i < P.scene_vec4; i += WG_THREADS) lds_scene[i] = P.scene[i];
         __syncthreads();
     }
-    const Lds S = make_lds<SCENE_LDS>(P, lds_scene, WG_TILES_X * WG_TILES_Y, threadIdx.x >> 6);
+    const Lds S = make_lds<SCENE_LDS, MESH>(P, lds_scene, WG_TILES_X * WG_TILES_Y, threadIdx.x >> 6);
 
     // ---- pixel of this lane ----------------------------------------------------------
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1228,12 +1223,13 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             r[10] = __uint_as_float(rng_pixel);
             r[11] = __uint_as_float(pixel);
         }
-        const int depth = (64 * RING_DEPTH) / n_hit;  // ring entries per slot (>= RING_DEPTH)
+        constexpr int ring_depth = MESH ? RING_DEPTH : RING_DEPTH_ANALYTIC;
+        const int depth = (64 * ring_depth) / n_hit;  // ring entries per slot (>= ring_depth)
         // sample -> ring row: a mask when depth is a power of two (full tiles: 4), else a real modulo (~20 instructions)
         const bool depth_pow2 = (depth & (depth - 1)) == 0;
         auto ring_row = [&](uint32_t s) { return depth_pow2 ? (s & (uint32_t)(depth - 1)) : (s % (uint32_t)depth); };
         float4* ring = S.ring;                        // [depth][n_hit] of (r, g, b, tag)
-        for (int i = lane; i < 64 * RING_DEPTH; i += 64) ring[i] = make_float4(0, 0, 0, __uint_as_float(0xFFFFFFFFu));
+        for (int i = lane; i < 64 * ring_depth; i += 64) ring[i] = make_float4(0, 0, 0, __uint_as_float(0xFFFFFFFFu));
         __builtin_amdgcn_wave_barrier();
 
         // owner state (lane k owns slot k)
@@ -1309,8 +1305,11 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 const unsigned long long readym = __builtin_amdgcn_ballot_w64(ready);
                 if (readym == 0ull) break;
 #if defined(SRT_STATS) && SRT_STATS == 4
-                SRT_STAT(4, 1);
-                SRT_STAT(5, __builtin_popcountll(readym));
+                {
+                    const int st_ready = __builtin_popcountll(readym);
+                    SRT_STAT(4, 1);
+                    SRT_STAT(5, st_ready);
+                }
 #endif
                 // long paths (Scene_indirect: 8 rays per sample) finish a few samples per step: a fold for fewer than a fifth of
                 // the slots waits for the next step's, unless a slot is out of ring capacity or the hand-out has ended
@@ -1402,9 +1401,12 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
 
             SRT_TICK(1);
 #if defined(SRT_STATS) && SRT_STATS == 4  // make dev STATS=4: lane occupancy of the pool (tests/pool_stats.py)
-            SRT_STAT(0, 1);
-            SRT_STAT(1, __builtin_popcountll(__builtin_amdgcn_ballot_w64(busy)));
-            SRT_STAT(6, n_hit);
+            {
+                const int st_busy = __builtin_popcountll(__builtin_amdgcn_ballot_w64(busy));  // (outside the macro: it runs under a lane-0 mask)
+                SRT_STAT(0, 1);
+                SRT_STAT(1, st_busy);
+                SRT_STAT(6, n_hit);
+            }
 #endif
             // ---- one bounce for every busy lane
             V3 o = v3(0, 0, 0);
@@ -1595,12 +1597,13 @@ __global__ void __launch_bounds__(64) pick_kernel(const KernelParams P, int px, 
 // learned order).  Any order gives the same image.
 constexpr int ORDER_BUCKETS = 16, ORDER_SORT_THREADS = 512;
 // Balance cost (srt_estimate_row_costs): TIME a block's pixels will take per sample, in 1/64 of the time of one analytic bounce
-// ray that meets no cluster.  Weights fitted by least squares on measured band times of configs 3 and 5 — the 135- / 270-row
-// bands an 8-rank run launches, equal split and shifted by half a band (tools/band_fit.py): a sample of a pixel
-// that traces nothing (the running mean is still evaluated sample by sample), a bounce ray, every cluster whose spheres are
-// tested exactly for it, a ray that goes through the mesh traversal (about ten analytic rays).  Whether a ray ENDS on a mesh
-// adds nothing once the traversal is counted (fitted weight 0).
-constexpr unsigned BAL_W_PIXEL = 2u, BAL_W_RAY = 64u, BAL_W_CAND = 11u, BAL_W_MESH_GO = 820u, BAL_W_MESH_HIT = 0u;
+// ray that meets no cluster.  Weights from least squares on measured band times of configs 3 and 5 — the bands an 8-rank run
+// launches (equal split, the same shifted by half a band) and the bands of the balanced 2- / 4- / 8-way splits themselves, with a
+// constant per launch in the model (tools/band_fit.py): a sample of a pixel that traces nothing costs next to
+// nothing (the constant had been hiding in this weight: 7 before), a bounce ray 64, every cluster whose spheres are tested
+// exactly for it 14, a ray that goes through the mesh traversal about sixteen analytic rays.  Whether a ray ENDS on a mesh adds
+// nothing once the traversal is counted (fitted weight 0).
+constexpr unsigned BAL_W_PIXEL = 2u, BAL_W_RAY = 64u, BAL_W_CAND = 14u, BAL_W_MESH_GO = 1000u, BAL_W_MESH_HIT = 0u;
 template <bool SCENE_LDS>
 __global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, uint32_t* cost, int blocks_x, int n_blocks, uint32_t* balance_cost, uint32_t* features) {
     extern __shared__ float4 lds_scene[];

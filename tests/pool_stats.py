@@ -33,6 +33,5 @@ o = list(out)
 steps = max(o[0], 1)
 print("%s%s spp %d rows %s: kernel %.3f ms (with counters), %d sample chunks, rays %d" % (a.scene, "+mesh" if a.mesh else "", a.spp, a.rows or "all", st.kernel_ms, st.sample_chunks, st.rays))
 print("  pool steps %d, busy lanes per step %.1f of 64, traced pixels per tile (step-weighted) %.1f" % (o[0], o[1] / steps, o[6] / steps))
-print("  closest_hit calls with clusters %d: active lanes %.1f, cluster items per call %.1f (%.2f per active lane), exact rounds per call %.2f" %
-      (o[3] and (o[3] * 0 + 1) and 0 or 0, 0, 0, 0, 0) if False else "  cluster items per step %.1f (%.2f per active lane), exact rounds per step %.2f" % (o[2] / steps, o[2] / max(o[7], 1), o[3] / steps))
+print("  cluster items per step %.1f (%.2f per active lane), exact rounds per step %.2f" % (o[2] / steps, o[2] / max(o[7], 1), o[3] / steps))
 print("  fold iterations per step %.2f, slots folded per iteration %.1f" % (o[4] / steps, o[5] / max(o[4], 1)))

@@ -141,6 +141,28 @@ def test_custom_environment(srt, oracle):
     oenv = oracle.Environment.from_buffer_copy(bytes(env))
     ofb, oacc, _ = oracle.render(C.cast(objs, C.POINTER(oracle.Object)), n, oenv, oracle.default_camera(), w, h, spp=2, bounces=4, seed=0)
     assert np.array_equal(pt.framebuffer(), ofb) and np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32))
+    # The environment lives in the scene image's constants block (round 3): set BEFORE the scene it must survive srt_set_scene,
+    # changed again AFTER it must be patched in place; negative components go through Color's clamp (Common.hpp:253-262);
+    # the preview shader reads the same rows.
+    pt2 = srt.PathTracer(w, h)
+    env.ground_color = (C.c_float * 3)(-0.5, 0.3, 0.0)
+    env.horizon_color = (C.c_float * 3)(2.0, -1.0, 0.25)
+    pt2.set_environment(env)
+    pt2.set_scene(objs, n)
+    pt2.set_camera(srt.default_camera())
+    oenv = oracle.Environment.from_buffer_copy(bytes(env))
+    for kw in (dict(spp=3, bounces=5), dict(spp=1, bounces=2, preview=True)):
+        pt2.render(seed=7, **kw)
+        ofb, oacc, _ = oracle.render(C.cast(objs, C.POINTER(oracle.Object)), n, oenv, oracle.default_camera(), w, h, seed=7, **kw)
+        assert np.array_equal(pt2.framebuffer(), ofb) and np.array_equal(pt2.accumulator().view(np.uint32), oacc.view(np.uint32))
+    env.sun_color = (C.c_float * 3)(-5, 400, 1)
+    env.sky_color = (C.c_float * 3)(3, 3, 3)
+    pt2.set_environment(env)
+    pt2.render(spp=2, bounces=3, seed=1)
+    oenv = oracle.Environment.from_buffer_copy(bytes(env))
+    ofb, oacc, _ = oracle.render(C.cast(objs, C.POINTER(oracle.Object)), n, oenv, oracle.default_camera(), w, h, spp=2, bounces=3, seed=1)
+    assert np.array_equal(pt2.framebuffer(), ofb) and np.array_equal(pt2.accumulator().view(np.uint32), oacc.view(np.uint32))
+    pt2.close()
 
 
 def test_host_renderer_sequences(srt, oracle):

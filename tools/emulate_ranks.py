@@ -52,7 +52,7 @@ print("config %d: whole frame on one GPU %.2f ms" % (a.config, whole), flush=Tru
 doc = {"config": a.config, "whole_frame_ms": whole, "splits": []}
 for N in (int(v) for v in a.ranks.split(",")):
     for mode in a.modes.split(","):
-        bands = stripes.partition_rows(H, N, row_cost if mode == "probe" else None, align=16 if mode == "probe" else 1)
+        bands = stripes.partition_rows(H, N, row_cost if mode == "probe" else None, align=8 if mode == "probe" else 1)
         ms = [band_ms(b) for b in bands]
         eff = sum(ms) / N / max(ms)
         print("config %d N=%d %-5s rows %s\n      ms %s | slowest %.2f  mean/slowest %.3f  (whole/N)/slowest %.3f" %
