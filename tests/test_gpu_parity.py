@@ -93,3 +93,42 @@ def test_object_count_limit(srt, oracle):
         pt.render(spp=1, bounces=1, seed=0)
     assert e.value.code == srt.capi.ERR_STATE
     pt.close()
+
+
+def test_colours_that_stress_the_clamps(srt, oracle):
+    """Round 3 removed every clamp0 of the reference that is provably the identity (kernel header: a clamp changes strictly negative
+    values only; sums and products of values that are never strictly negative stay so) and clamps the material / environment
+    colours once, when the scene image is built.  The oracle still executes every clamp of Color's constructor
+    (Common.hpp:253-262).  Negative, -0.0, large and tiny colour components — in materials, in the environment and in an
+    accumulator handed in by the caller — must give the same bits.  (No NaN / infinity here: x86 and gfx950 give NaNs different
+    payloads, which the byte-level comparison of float accumulators would report although both are "the" NaN.)"""
+    objs = oracle.load_scene_json_py(scene_path("Scene_indirect"))
+    nasty = [(-1.0, 0.5, 2.0), (-0.0, 0.0, 1.0), (1e6, 1e-30, -1e6), (3.0, 0.25, -0.0), (1e-38, 1.0, -3.0), (0.0, -0.0, 7.5)]
+    for i, o in enumerate(objs):
+        if o.get("type") in (oracle.OBJ_SPHERE, oracle.OBJ_BOX):
+            o["base"] = nasty[i % len(nasty)]
+            o["emissive"] = nasty[(i + 2) % len(nasty)] if i % 3 == 0 else o.get("emissive", (0, 0, 0))
+            o["specular"] = nasty[(i + 4) % len(nasty)] if i % 4 == 0 else o.get("specular", (1, 1, 1))
+    oarr, n = oracle.make_objects(objs)
+    w, h = 96, 64
+    env = srt.default_environment()
+    env.sky_color = (C.c_float * 3)(-2.0, 3.5, 10.0)
+    env.ground_color = (C.c_float * 3)(0.08, -0.0, 0.03)
+    env.sun_color = (C.c_float * 3)(500.0, -500.0, 1e6)
+    oenv = oracle.Environment.from_buffer_copy(bytes(env))
+    pt = srt.PathTracer(w, h)
+    pt.set_environment(env)
+    pt.set_scene(C.cast(oarr, C.POINTER(srt.Object)), n)
+    pt.set_camera(srt.default_camera())
+    rng = np.random.default_rng(3)
+    acc0 = rng.uniform(-2.0, 5.0, (h, w, 4)).astype(np.float32)  # a caller's accumulator with negative entries
+    acc0[::7, ::5] = -0.0
+    pt.write_accumulator(acc0)
+    pt.render(spp=3, bounces=6, seed=5, first_sample=4, reset=False)
+    ofb, oacc, _ = oracle.render(oarr, n, oenv, oracle.default_camera(), w, h, spp=3, bounces=6, seed=5, first_sample=4, reset=False, accumulator=acc0)
+    assert np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32)), int((pt.accumulator().view(np.uint32) != oacc.view(np.uint32)).sum())
+    assert np.array_equal(pt.framebuffer(), ofb)
+    pt.render(spp=40, bounces=8, seed=6)  # sample-chunk-free full launch from a reset, many samples
+    ofb, oacc, _ = oracle.render(oarr, n, oenv, oracle.default_camera(), w, h, spp=40, bounces=8, seed=6)
+    assert np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32)) and np.array_equal(pt.framebuffer(), ofb)
+    pt.close()
