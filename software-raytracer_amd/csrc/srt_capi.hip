@@ -324,7 +324,7 @@ static int set_scene_impl(srt_context* ctx, const srt_object* objects, size_t co
         // instantiation, same bits); the pick kernel runs one wave, so it is judged separately
         const size_t image_bytes = (size_t)L.total_vec4 * sizeof(float4);
         const size_t mesh_scratch = has_mesh ? (size_t)(srt::WG_MESH_SCRATCH_BYTES) : 0;
-        ctx->scene_in_lds[v] = image_bytes + (has_mesh ? (size_t)srt::WG_SCRATCH_BYTES : (size_t)srt::WG_SCRATCH_BYTES_ANALYTIC) + mesh_scratch <= (size_t)ctx->lds_limit_bytes;
+        ctx->scene_in_lds[v] = image_bytes + (size_t)srt::WG_SCRATCH_BYTES + mesh_scratch <= (size_t)ctx->lds_limit_bytes;
         ctx->pick_in_lds[v] = image_bytes + srt::WAVE_SCRATCH_BYTES + srt::MESH_WAVE_BYTES <= (size_t)ctx->lds_limit_bytes;
         if (ctx->h_scene[v].size() > ctx->scene_capacity_vec4[v] || !ctx->d_scene[v]) {
             if (ctx->d_scene[v]) SRT_HIP(ctx, hipFree(ctx->d_scene[v]));
@@ -353,7 +353,7 @@ static int set_scene_impl(srt_context* ctx, const srt_object* objects, size_t co
     ctx->d_bvh_gidpos = nullptr;
     if (ctx->mesh_image.n_tris > 0) {
         // strict depth-first traversal (the kernel's last resort) keeps at most 7 entries per level
-        if (7 * ctx->mesh_image.max_depth + 8 > srt::MESH_QN)
+        if (7 * ctx->mesh_image.max_depth + 80 > srt::MESH_Q)
             return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: BVH too deep (%d levels)", ctx->mesh_image.max_depth);
         if (ctx->mesh_image.n_nodes >= (1 << 26) || ctx->mesh_image.n_tris >= (1 << 24))  // (item encoding of the traversal queues)
             return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: mesh too large (%d triangles)", ctx->mesh_image.n_tris);
@@ -540,7 +540,7 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
     K.ray_counter = ctx->d_rays;
 
     lds_bytes = (ctx->scene_in_lds[img] ? (size_t)(SL.total_vec4 > 0 ? SL.total_vec4 : 1) * sizeof(float4) : 0) +
-                (ctx->mesh_image.n_tris > 0 ? srt::WG_SCRATCH_BYTES + srt::WG_MESH_SCRATCH_BYTES : srt::WG_SCRATCH_BYTES_ANALYTIC);
+                srt::WG_SCRATCH_BYTES + (ctx->mesh_image.n_tris > 0 ? srt::WG_MESH_SCRATCH_BYTES : 0);
     return SRT_OK;
 }
 
@@ -816,9 +816,9 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
         else hipLaunchKernelGGL(k_hbm, grid, block, lds_bytes, ctx->stream, K);
     };
     if (K.n_tris > 0)  // EXTENSION: scenes with triangle meshes use the BVH-enabled instantiation
-        launch(srt::pathtrace_kernel<3, true, true, false, false>, srt::pathtrace_kernel<3, true, true, true, false>,
-               srt::pathtrace_kernel<3, true, true, false, true>, srt::pathtrace_kernel<3, true, false, false, false>,
-               srt::pathtrace_kernel<3, true, false, true, false>, srt::pathtrace_kernel<3, true, false, false, true>);
+        launch(srt::pathtrace_kernel<4, true, true, false, false>, srt::pathtrace_kernel<3, true, true, true, false>,
+               srt::pathtrace_kernel<4, true, true, false, true>, srt::pathtrace_kernel<4, true, false, false, false>,
+               srt::pathtrace_kernel<3, true, false, true, false>, srt::pathtrace_kernel<4, true, false, false, true>);
 #ifdef SRT_DEV  // occupancy variants for A/B timing; never in the shipped library
     else if (use == 1 && in_lds && !multi && !defer)
         hipLaunchKernelGGL((srt::pathtrace_kernel<4, false>), grid, block, lds_bytes, ctx->stream, K);

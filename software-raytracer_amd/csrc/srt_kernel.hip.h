@@ -107,19 +107,17 @@ constexpr int WG_W = TILE_W * WG_TILES_X, WG_H = TILE_H * WG_TILES_Y;
 // per-wave LDS scratch behind the scene image: work list of (ray lane, cluster) items + one
 // 64-bit result slot per lane (balanced phase 2 of closest_hit)
 constexpr int WORK_MAX = 512;
-// ring entries per slot when all 64 pixels of the tile are traced (powers of two).  The mesh kernel (3 waves per SIMD, its LDS is
-// what holds it there) keeps 4.  The analytic kernel runs FIVE waves per SIMD since round 3 (96 VGPRs): five workgroups' LDS fit
-// into a CU's 160 KiB only with 2 entries per slot — with 4 waves per SIMD the shorter ring costs 3..7 %, the fifth wave wins
-// that back and more where paths are long: Scene_indirect -3.7 %, Scene3 -4.5 %, Scene1 / Scene1_reflection +-0.
-constexpr int RING_DEPTH = 4, RING_DEPTH_ANALYTIC = 2;
+// ring entries per slot when all 64 pixels of the tile are traced (a power of two).  Round 3: 2 (4 before).  The analytic kernel
+// runs FIVE waves per SIMD (96 VGPRs) and the mesh kernel FOUR (128): that many workgroups' LDS fit into a CU's 160 KiB only
+// with the shorter ring.  With unchanged occupancy the shorter ring costs 3..7 % (a slot whose sample runs long can have only one
+// more in flight); the extra wave wins that back and more: Scene_indirect -4.4 %, Scene3 -4.5 %, Scene1 -1.5 %, config 4 -5 %.
+constexpr int RING_DEPTH = 2;
 // per-wave: 64 result slots (8 B) | work list (2 B) | 64 pixel records (48 B) | ring (16 B)
 constexpr int WAVE_SCRATCH_BYTES = 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4 + 64 * RING_DEPTH * 16;
-constexpr int WAVE_SCRATCH_BYTES_ANALYTIC = 64 * 8 + WORK_MAX * 2 + 64 * 12 * 4 + 64 * RING_DEPTH_ANALYTIC * 16;
 constexpr int WG_SCRATCH_BYTES = WAVE_SCRATCH_BYTES * WG_TILES_X * WG_TILES_Y;
-constexpr int WG_SCRATCH_BYTES_ANALYTIC = WAVE_SCRATCH_BYTES_ANALYTIC * WG_TILES_X * WG_TILES_Y;
 // extra per-wave LDS of the mesh kernel: node LIFO + leaf queue of the cooperative BVH traversal
 // (sized so that three workgroups of the mesh kernel still fit into a CU's 160 KiB next to the Scene1-sized image)
-constexpr int MESH_QN = 448, MESH_QL = 320;
+constexpr int MESH_Q = 512;  // entries of the traversal buffer: the node LIFO grows up from its bottom, the leaf queue down from its top
 constexpr float MESH_T_MIN_CULL = 0.0099f;  // just below the smallest valid triangle distance, (float)0.01
 #ifdef SRT_STATS  // development build only (make STATS=1|2): traversal counters read by srt_debug_read_stats
 __device__ unsigned long long g_stats[8];
@@ -143,7 +141,7 @@ struct Prof {
 constexpr int WAVE_LOG_MAX = 1 << 17;
 __device__ unsigned long long g_wave_log[6 * WAVE_LOG_MAX];
 #endif
-constexpr int MESH_WAVE_BYTES = (MESH_QN + MESH_QL) * 4;
+constexpr int MESH_WAVE_BYTES = MESH_Q * 4;
 constexpr int WG_MESH_SCRATCH_BYTES = MESH_WAVE_BYTES * WG_TILES_X * WG_TILES_Y;
 
 // inclusive prefix sum over the 64 lanes of a wave (all lanes active): four shifts inside the rows of 16, then the row totals
@@ -196,7 +194,7 @@ struct Lds {
     unsigned short* work;     // this wave's work list
     float* pix;               // this wave's 64 pixel records (12 floats each)
     float4* ring;             // this wave's sample-colour ring
-    unsigned* meshq;          // mesh kernel only: node LIFO [MESH_QN] then leaf queue [MESH_QL]
+    unsigned* meshq;          // mesh kernel only: [MESH_Q] node LIFO from the bottom, leaf queue from the top
     __device__ __forceinline__ float4 sphere(int p) const { return v[p]; }
     __device__ __forceinline__ float4 bound(int k) const { return v[off_bounds + k]; }
     __device__ __forceinline__ float4 box_c(int j) const { return v[off_box + 2 * j]; }
@@ -533,7 +531,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             // rule — and doubles as the culling distance.  The merge is idempotent, so when a queue would
             // overflow the batch is simply abandoned and redone with fewer rays at a time; one ray
             // popping one item per round (strict depth-first) is bounded by 7 * depth + 8 entries, which
-            // the host checks against MESH_QN.
+            // the host checks against MESH_Q.
             //
             // Deferral (path pool only): a mesh phase costs the wave some seven rounds of ~350 instructions however
             // few rays take part, and most phases would be started by two or three stray bounce rays.  So
@@ -553,8 +551,8 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             }
             if (pend != 0ull) {
                 const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-                unsigned* qn = S.meshq;
-                unsigned* ql = S.meshq + MESH_QN;
+                unsigned* qn = S.meshq;               // node item i at qn[i]
+                unsigned* qlt = S.meshq + MESH_Q - 1;  // leaf item i at qlt[-i]: both queues share the buffer's free middle
                 auto okey = [](float t) {  // order-preserving float -> uint
                     unsigned u = __float_as_uint(t + 0.0f);
                     return u ^ ((u & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);
@@ -594,7 +592,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                     const unsigned long long selmask = __builtin_amdgcn_ballot_w64(sel);
                     int nN = 0, nL = 0;
                     overflow = false;
-                    push(sel, (unsigned)lane << 26, qn, nN, MESH_QN);
+                    push(sel, (unsigned)lane << 26, qn, nN, MESH_Q);
                     __builtin_amdgcn_wave_barrier();
                     while (!overflow && (nN > 0 || nL > 0)) {
                         // ---- one round pops items of ONE queue.  (Tried and measured slower on config 4: serving both queues in
@@ -613,9 +611,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                                 logP = nN <= 8 ? 3 : nN <= 16 ? 2 : nN <= 32 ? 1 : 0;
                                 takeN = nN < (64 >> logP) ? nN : (64 >> logP);
                                 // leave room for the expected pushes (about 3 per item)
-                                int room = (MESH_QN - nN) / 3;
-                                const int lroom = (MESH_QL - nL) / 3;
-                                room = room < lroom ? room : lroom;
+                                int room = (MESH_Q - nN - nL) / 6;  // (about 3 pushes per item to either queue)
                                 room = room < 8 ? 8 : room;
                                 takeN = takeN < room ? takeN : room;
                             }
@@ -711,7 +707,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                             const unsigned incl = wave_inclusive_scan(both);
                             const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63), excl = incl - both;
                             const int totN = (int)(total & 0xFFFFu), totL = (int)(total >> 16);
-                            if (nN + totN > MESH_QN || nL + totL > MESH_QL) {
+                            if (nN + totN + nL + totL > MESH_Q) {
                                 overflow = true;
                             } else {
                                 if (totN > 0) {  // surviving inner children -> node LIFO
@@ -737,7 +733,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                                             const unsigned first = first_tri + (unsigned)__builtin_popcount(leafmask & below) + (unsigned)__builtin_popcount(cf & 0x5555u) +
                                                                    2u * (unsigned)__builtin_popcount(cf & 0xAAAAu);
                                             const unsigned c2 = 2u * (unsigned)__builtin_ctz(bit);
-                                            ql[w++] = tag | (first * 4u + ((counts >> c2) & 3u));
+                                            qlt[-(w++)] = tag | (first * 4u + ((counts >> c2) & 3u));
                                             ml &= ml - 1u;
                                         }
                                     }
@@ -760,7 +756,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
 #endif
                             const int slotL = lane >> logL, subL = lane & ((1 << logL) - 1);
                             const bool onL = slotL < takeL;
-                            const unsigned item = onL ? ql[nL + slotL] : 0u;
+                            const unsigned item = onL ? qlt[-(nL + slotL)] : 0u;
                             const int src = (int)(item >> 26), code = (int)(item & 0x3FFFFFFu);
                             const int lcnt = (code & 3) + 1;  // leaf items: (first triangle) * 4 + (count - 1)
                             const float4* rowp = P.bvh_tris + 3 * (size_t)((code >> 2) + (subL < lcnt ? subL : 0));  // (idle lanes: triangle 0)
@@ -804,7 +800,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                     } else if (batch > 1) {
                         batch = batch > 4 ? batch >> 2 : 1;
                     } else {
-                        strict = true;  // cannot overflow: the host bounds 7 * depth + 8 by MESH_QN
+                        strict = true;  // cannot overflow: the host bounds 7 * depth + 80 (the stack + the leaves that may wait) by MESH_Q
 #ifdef SRT_STATS
                         if (SRT_STATS == 1) SRT_STAT(7, 1);
 #endif
@@ -949,9 +945,9 @@ __device__ __forceinline__ void store_pixel(const KernelParams& P, uint32_t pix,
 // [waves x MESH_WAVE_BYTES (mesh kernel only)].  SCENE_LDS == false is the fallback for scene images
 // that do not fit next to the scratch (thousands of analytic primitives): the same image is then read
 // from HBM/L2 through the same accessors — slower per test, same arithmetic, same bits.
-template <bool SCENE_LDS, bool MESH_LAYOUT = true>
+template <bool SCENE_LDS>
 __device__ __forceinline__ Lds make_lds(const KernelParams& P, float4* lds, int waves, int wave) {
-    constexpr int stride = MESH_LAYOUT ? WAVE_SCRATCH_BYTES : WAVE_SCRATCH_BYTES_ANALYTIC;  // (the analytic pool kernel's ring is shorter)
+    constexpr int stride = WAVE_SCRATCH_BYTES;
     char* wg = reinterpret_cast<char*>(lds + (SCENE_LDS ? P.scene_vec4 : 0));
     char* scratch = wg + wave * stride;
     const float4* image;
@@ -985,7 +981,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         for (int i = threadIdx.x; i < P.scene_vec4; i += WG_THREADS) lds_scene[i] = P.scene[i];
         __syncthreads();
     }
-    const Lds S = make_lds<SCENE_LDS, MESH>(P, lds_scene, WG_TILES_X * WG_TILES_Y, threadIdx.x >> 6);
+    const Lds S = make_lds<SCENE_LDS>(P, lds_scene, WG_TILES_X * WG_TILES_Y, threadIdx.x >> 6);
 
     // ---- pixel of this lane ----------------------------------------------------------
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1223,7 +1219,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             r[10] = __uint_as_float(rng_pixel);
             r[11] = __uint_as_float(pixel);
         }
-        constexpr int ring_depth = MESH ? RING_DEPTH : RING_DEPTH_ANALYTIC;
+        constexpr int ring_depth = RING_DEPTH;
         const int depth = (64 * ring_depth) / n_hit;  // ring entries per slot (>= ring_depth)
         // sample -> ring row: a mask when depth is a power of two (full tiles: 4), else a real modulo (~20 instructions)
         const bool depth_pow2 = (depth & (depth - 1)) == 0;
@@ -1277,6 +1273,8 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             // others — a further iteration for their sake costs the whole wave a fold.  Once the hand-out has ended, or nothing
             // runs, everything ready is folded.
             const bool drain = __builtin_amdgcn_ballot_w64(busy) == 0ull || __builtin_amdgcn_ballot_w64(own_next < count) == 0ull;
+            // (Round 3, with the ring of two entries: folding eagerly — every step, up to `depth` iterations, no waiting for a
+            // fifth of the slots — frees ring capacity sooner but costs more folds than it gains: +2..+7 %.)
             const int fold_its = drain || fold_pace > depth ? depth : fold_pace;
             for (int it = 0; it < fold_its; ++it) {
                 bool ready = false;
@@ -1543,6 +1541,10 @@ __global__ void __launch_bounds__(256) fold_kernel(const KernelParams P, int til
     const int y = P.y0 + by * WG_H + (bit / TILE_W) * WG_TILES_Y + (wave / WG_TILES_X);
     const uint32_t pixel = (uint32_t)(x + y * P.width);
     float4 acc = (P.flags & 1u) ? make_float4(0, 0, 0, 0) : P.accumulator[pixel];
+    // (Round 3 tried the layout [tile][group of 8 samples][slot][8 samples] — a 128-byte line = 8 consecutive samples of ONE slot,
+    // written by one lane — to get the sample buffer's lines to memory in one piece: WRITE_SIZE of config 3's floor band stayed at
+    // 2.6x the bytes stored (5.5 GB for 2.1 GB: a line's eight 16-byte writes are many steps apart in either layout, longer than
+    // 512 waves' open lines stay in an XCD's 4 MB L2), and this kernel's strided reads made the middle band 5 % slower.)
     const float4* row = P.sample_rows + tile_id * P.sample_count * 64 + lane;
     const uint32_t n = P.sample_count;
     uint32_t s = 0;

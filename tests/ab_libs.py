@@ -24,6 +24,7 @@ WORK = {  # name: scene, mesh, width, height, spp, bounces, memory rows (None = 
     "c3r4": ("Scene1", 0, 1920, 1080, 512, 8, (540, 675)),
     "c3r7": ("Scene1", 0, 1920, 1080, 512, 8, (945, 1080)),
     "c5r4": ("Scene1", 224, 3840, 2160, 1024, 16, (1080, 1350)),
+    "c5r5": ("Scene1", 224, 3840, 2160, 1024, 16, (1350, 1620)),
     "c3n72": ("Scene1", 0, 1920, 1080, 512, 8, (744, 816)),    # narrow bands of a cost-balanced 8-rank split of config 3
     "c3n64": ("Scene1", 0, 1920, 1080, 512, 8, (816, 880)),
     "c3n48": ("Scene1", 0, 1920, 1080, 512, 8, (936, 984)),
