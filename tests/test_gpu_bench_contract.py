@@ -48,6 +48,13 @@ def test_two_rank_rehearsal(balance, port):
     bands = d["config"]["bands"]
     assert bands[0][0] == 0 and bands[-1][1] == 360 and bands[0][1] == bands[1][0]
     assert len(d["per_rank"]) == 2
+    # the roofline of an N > 1 line is summed over the ranks: N GPUs' peak, all ranks' lane-ops over the slowest rank's launch time
+    rf = d["roofline"]
+    assert abs(rf["peak"] - 2 * 78.6432) < 1e-6 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert abs(rf["kernel_ms"] - max(p["kernel_ms"] for p in d["per_rank"])) < 1e-9
+    ops = sum(p["algorithmic_laneops"] for p in d["per_rank"])
+    assert abs(rf["achieved"] * 1e12 - ops / (rf["kernel_ms"] * 1e-3)) / (rf["achieved"] * 1e12) < 1e-9
+    assert all(p["frac"] > 0 for p in d["per_rank"])
     if balance == "equal":
         assert bands[0][1] == 180 and "calibration_launches" not in d["config"]
     else:
