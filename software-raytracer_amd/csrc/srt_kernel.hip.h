@@ -1263,6 +1263,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         // fold point (ring capacity); slots do not wait for each other.
         uint32_t own_next = own_done;
         int rot = 0;  // wave-uniform rotation of the slot priority
+        unsigned handed = 0;  // wave-uniform: samples handed out so far (n_hit x the mean own_next)
         const int fold_pace = (63 + n_hit) / n_hit;
 
         while (true) {
@@ -1345,10 +1346,23 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 const int nfree = __builtin_popcountll(freem), ncan = __builtin_popcountll(canm);
                 // slot priority rotates every round so that all slots advance at the same pace
                 // (a fixed order would starve the high slots and leave them for a thin tail)
+                // — and, of the slots that can, those at or behind the wave's mean hand-out point go first: with a ring of two
+                // entries a slot that fell behind stalls the tail of the tile (lanes idle while its last samples run one after
+                // the other); serving the laggards first keeps the slots level, ~5 % fewer pool steps (tests/pool_stats.py)
                 rot = (rot + 23) & 63;
-                const unsigned long long canr = rot ? ((canm >> rot) | (canm << (64 - rot))) : canm;
-                const int lr = (lane - rot) & 63;
-                const int crank = __builtin_popcountll(canr & ((1ull << lr) - 1ull));
+                const unsigned long long lagm = __builtin_amdgcn_ballot_w64(can && __umul24(own_next, (unsigned)n_hit) <= handed);
+                const unsigned long long restm = canm & ~lagm;
+                // rank inside a tier, counted cyclically from lane `rot`: bits below the lane, minus the bits below `rot`,
+                // plus the whole tier for the lanes that wrapped (all 32-bit: no per-lane 64-bit mask)
+                const unsigned long long lowrot = (1ull << rot) - 1ull;
+                const int nlag = __builtin_popcountll(lagm);
+                const bool lag = (lagm >> lane) & 1ull;
+                const unsigned long long tierm = lag ? lagm : restm;
+                const int tier_below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(tierm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)tierm, 0u));
+                const int tier_off = lag ? -__builtin_popcountll(lagm & lowrot) : nlag - __builtin_popcountll(restm & lowrot);
+                const int tier_wrap = lane < rot ? (lag ? nlag : ncan - nlag) : 0;
+                const int crank = tier_below + tier_off + tier_wrap;
+                handed += (unsigned)(nfree < ncan ? nfree : ncan);
                 const int frank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(freem >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)freem, 0u));
                 unsigned* match = reinterpret_cast<unsigned*>(S.work);  // [64] of (sample << 6 | slot), ~0 = nothing
                 unsigned m = 0xFFFFFFFFu;
