@@ -43,6 +43,7 @@ sys.path.insert(0, ROOT)
 SEED, FOV = 0, 55
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 128 * 2.4e9      # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz, no FMA credit
+BAND_ALIGN = 2                             # rows: boundaries of the cost-balanced split (8 cost 2-3 points of balance at N = 8)
 NODE_OPS, TRI_OPS = 240, 40                # lane-ops per BVH node item (8 child boxes) / triangle test
 
 # BASELINE.json configs, 1-based.  mesh = tessellation of Scene1's big ball (224 -> 99,904 triangles)
@@ -127,12 +128,12 @@ def main():
     ap.add_argument("--mesh", type=int, default=None, metavar="N", help="EXTENSION: replace Scene1's big ball by an N x N tessellation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the bounded CPU sample (16 spp at 1080p = about 20 s of CPU work)")
-    ap.add_argument("--balance", default="probe", choices=["equal", "probe", "cost"],
+    ap.add_argument("--balance", default="probe", choices=["equal", "probe"],
                     help="row-stripe split for N > 1 (and for --rank): 'probe' (default): contiguous bands of equal estimated cost from the "
-                         "library's device-side probe (srt_estimate_row_costs, ~0.1 ms, deterministic: no collective, no extra launch) + one "
-                         "dist.gather of bands padded to the tallest; 'equal': bands of equal height + one in-place dist.gather (north_star's "
-                         "literal form; on sky-over-floor scenes the slowest of 8 takes 2.2x the mean); 'cost': a 1-spp ray-count probe per "
-                         "8 rows and one calibration launch with an all_gather (their cost is reported in the JSON; never inside the timed region)")
+                         "library's device-side probe (srt_estimate_row_costs: the path pool over a quarter of the pixels for 32 samples, loop "
+                         "trips counted, not timed — deterministic: no collective, no launch of the workload) + one dist.gather of bands padded "
+                         "to the tallest; 'equal': bands of equal height + one in-place dist.gather (north_star's literal form; on "
+                         "sky-over-floor scenes the slowest of 8 takes 2.2x the mean)")
     ap.add_argument("--gather", default="padded", choices=["padded", "p2p"],
                     help="cost-balanced (unequal) bands only: one dist.gather of bands padded to the tallest, or one grouped isend/irecv")
     args = ap.parse_args()
@@ -224,46 +225,13 @@ def main():
     if n_parts > 1 and args.balance == "probe":
         t_cal = time.perf_counter()
         row_cost = pt.estimate_row_costs(bounces, SEED)
-        bands = stripes.partition_rows(H, n_parts, row_cost, align=8)
+        bands = stripes.partition_rows(H, n_parts, row_cost, align=BAND_ALIGN)
         calibration = {"calibration_launches": 0, "probe_launches": 1, "calibration_ms": (time.perf_counter() - t_cal) * 1e3,
-                       "calibration": "none: srt_estimate_row_costs is one device-side probe of 1/16 of the pixels at one sample (no launch of the workload), same numbers on every rank"}
+                       "calibration": "none: srt_estimate_row_costs is one device-side probe — the path pool over a quarter of the pixels for the first 32 samples, counting loop trips, no timing; the same numbers on every rank"}
         rb, re = bands[share[0] if share else rank]
     elif share:
         bands = stripes.partition_rows(H, share[1])
         rb, re = bands[share[0]]
-    elif world > 1 and args.balance == "cost":
-        # opt-in: per-row cost from a 1-spp ray-count probe (deterministic, same on all ranks), refined by ONE
-        # calibration launch at the real sample count; its cost is reported, it is never inside the timed region
-        t_cal = time.perf_counter()
-        launches = 0
-        row_cost = []
-        probe = new_tracer()
-        band = 8
-        for r0 in range(0, H, band):
-            r1 = min(r0 + band, H)
-            probe.render(spp=1, bounces=bounces, seed=SEED, rows=(r0, r1), count_rays=True)
-            st = probe.stats()
-            launches += 1
-            # cost model: secondary rays dominate; +0.05 per pixel of fixed work
-            c = (st.rays - W * (r1 - r0)) + 0.05 * W * (r1 - r0)
-            row_cost += [c / (r1 - r0)] * (r1 - r0)
-        probe.close()
-        bands = stripes.partition_rows(H, world, row_cost, align=8)
-        a, b = bands[rank]
-        pt.render(spp=spp, bounces=bounces, seed=SEED, first_sample=1, reset=True, rows=(a, b))
-        launches += 1
-        t_loc = torch.tensor([pt.stats().kernel_ms], dtype=torch.float64, device=cdev)
-        t_all = [torch.zeros_like(t_loc) for _ in range(world)]
-        dist.all_gather(t_all, t_loc)
-        times = [float(t.item()) for t in t_all]
-        if max(times) > 1.02 * (sum(times) / world):  # rescale every band's rows to its measured time, split again
-            for k, (x, y) in enumerate(bands):
-                f = times[k] / (sum(row_cost[x:y]) or 1.0)
-                for r in range(x, y):
-                    row_cost[r] *= f
-            bands = stripes.partition_rows(H, world, row_cost, align=1)
-        calibration = {"calibration_launches": launches, "calibration_ms": (time.perf_counter() - t_cal) * 1e3}
-        rb, re = bands[rank]
     else:
         bands = stripes.partition_rows(H, world)
         rb, re = bands[rank]

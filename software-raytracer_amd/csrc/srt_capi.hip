@@ -641,7 +641,17 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             if (getenv("SRT_DEBUG_CHUNKS")) fprintf(stderr, "chunks: dearest %u sum %.0f blocks %lld slots %.0f ratio %.3f -> c %lld\n", ctx->cost_max, ctx->cost_sum, wg8, slots, ratio, c);
 #endif
         }
-        if (c > p->sample_count / 16) c = p->sample_count / 16;
+        // Analytic scenes, round 3 (five resident workgroups per CU, ring of two): at least ten rounds of workgroups, whatever the
+        // record says — a band of evenly dear blocks has a ratio below 1 and got 2..4 chunks, i.e. 3.4 rounds with the last one
+        // 40 % full: Scene3's rows 270-405 at 512 spp 5.8 ms with 4 chunks, 4.9 with 8, 4.35 with 16; Scene_indirect's 135-row
+        // bands 28.4 -> 26.4 ms, its 540-row half 110 -> 106; config 3's 64..144-row bands -2..-7 %.  Chunks of fewer than 24
+        // samples cost more than they balance (every chunk stages the scene and repeats the primary hits).
+        const long long min_chunk = K.n_tris > 0 ? 16 : 24;
+        if (K.n_tris == 0) {
+            const long long c_fill = (10LL * 5 * ctx->cu_count + wg8 - 1) / wg8;
+            if (c < c_fill) c = c_fill;
+        }
+        if (c > p->sample_count / min_chunk) c = p->sample_count / min_chunk;
         // A mesh launch that the rule leaves in ONE piece keeps full 8 x 8 tiles: the small tiles chosen above for launches of few
         // blocks (tuned in round 1 on analytic scenes at 16..63 spp) cost the mesh kernel more than they balance — config 5's
         // floor bands of a cost-balanced 8-rank split (1024 spp, 128 / 208 rows): 107 -> 92 ms, 90 -> 78 ms (round 3).
@@ -783,9 +793,9 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             const size_t image_bytes = (size_t)(K.scene_vec4 > 0 ? K.scene_vec4 : 1) * sizeof(float4);
             const size_t est_lds = (ctx->pick_in_lds[img] ? image_bytes : 0) + srt::WAVE_SCRATCH_BYTES + srt::MESH_WAVE_BYTES;
             if (ctx->pick_in_lds[img])
-                hipLaunchKernelGGL(srt::block_cost_kernel<true>, dim3((unsigned)((nwg + 3) / 4)), dim3(64), est_lds, ctx->stream, K, ctx->d_wg_est, (int)grid.x, (int)nwg, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                hipLaunchKernelGGL(srt::block_cost_kernel<true>, dim3((unsigned)((nwg + 3) / 4)), dim3(64), est_lds, ctx->stream, K, ctx->d_wg_est, (int)grid.x, (int)nwg);
             else
-                hipLaunchKernelGGL(srt::block_cost_kernel<false>, dim3((unsigned)((nwg + 3) / 4)), dim3(64), est_lds, ctx->stream, K, ctx->d_wg_est, (int)grid.x, (int)nwg, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                hipLaunchKernelGGL(srt::block_cost_kernel<false>, dim3((unsigned)((nwg + 3) / 4)), dim3(64), est_lds, ctx->stream, K, ctx->d_wg_est, (int)grid.x, (int)nwg);
             hipLaunchKernelGGL(srt::smooth_cost_kernel, dim3((unsigned)((nwg + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_wg_est, ctx->d_wg_est + nwg, (int)nwg, (int)grid.x);
             hipLaunchKernelGGL(srt::order_sort_kernel, dim3(1), dim3(srt::ORDER_SORT_THREADS), 0, ctx->stream, ctx->d_wg_est + nwg, ctx->d_wg_order, (int)nwg);
             if (hipGetLastError() == hipSuccess) {
@@ -982,38 +992,63 @@ int srt_read_accumulator(srt_context* ctx, float* dst_rgba) {
     return SRT_OK;
 }
 
-// the device-side probe of block_cost_kernel over the WHOLE frame: per 16 x 16 block its balance cost and, for the development
-// library's fitting tool, the raw feature sums (8 words per block)
-static int run_block_probe(srt_context* ctx, int max_bounces, uint32_t seed, std::vector<uint32_t>& balance, std::vector<uint32_t>* features, int& bx, int& by) {
+// The balance probe: the PROBE instantiation of pathtrace_kernel runs the real path pool over the WHOLE frame for the frame's
+// first PROBE_SAMPLES samples — nothing of the frame is read or written — and every wave adds what its loops did (srt::TALLY_*:
+// pool steps, groups of exactly tested spheres, second halves of the sphere test, BVH rounds, folds, traced and untraced pixels)
+// to its 16 x 16 block's counters.  Counts, not times: the same on every GPU and in every run.  A whole frame at 8 samples is
+// 1.6 % of config 3's launch, 0.8 % of config 5's.
+constexpr int PROBE_SAMPLES = 32;
+static int run_pool_probe(srt_context* ctx, int max_bounces, uint32_t seed, std::vector<uint32_t>& counts, int& bx, int& by) {
     SRT_HIP(ctx, hipSetDevice(ctx->device));
     const int W = ctx->width, H = ctx->height;
     srt_render_params p{};
-    p.row_begin = 0, p.row_end = H, p.first_sample = 1, p.sample_count = 1, p.max_bounces = max_bounces, p.seed = seed;
+    p.row_begin = 0, p.row_end = H, p.first_sample = 1, p.sample_count = PROBE_SAMPLES, p.max_bounces = max_bounces, p.seed = seed;
+    p.flags = SRT_RENDER_RESET;
     srt::KernelParams K;
     size_t lds_bytes = 0;
     int use = 0, img = 0;
     fill_kernel_params(ctx, &p, K, lds_bytes, use, img);
+    K.flags = SRT_RENDER_RESET;
     K.tile_h = srt::TILE_H;
+    K.accumulator = nullptr, K.framebuffer = nullptr, K.ray_counter = nullptr;  // the probe touches none of them
     bx = (W + srt::WG_W - 1) / srt::WG_W, by = (H + srt::WG_H - 1) / srt::WG_H;
-    const int n = bx * by;
+    const size_t n = (size_t)bx * by, words = n * srt::TALLY_N;
     uint32_t* d = nullptr;
-    SRT_HIP(ctx, hipMalloc((void**)&d, (size_t)(2 + (features ? 8 : 0)) * n * sizeof(uint32_t)));
-    uint32_t* d_feat = features ? d + 2 * (size_t)n : nullptr;
-    const size_t image_bytes = (size_t)(K.scene_vec4 > 0 ? K.scene_vec4 : 1) * sizeof(float4);
-    const size_t est_lds = (ctx->pick_in_lds[img] ? image_bytes : 0) + srt::WAVE_SCRATCH_BYTES + srt::MESH_WAVE_BYTES;
-    if (ctx->pick_in_lds[img])
-        hipLaunchKernelGGL(srt::block_cost_kernel<true>, dim3((unsigned)((n + 3) / 4)), dim3(64), est_lds, ctx->stream, K, d, bx, n, d + n, d_feat);
-    else
-        hipLaunchKernelGGL(srt::block_cost_kernel<false>, dim3((unsigned)((n + 3) / 4)), dim3(64), est_lds, ctx->stream, K, d, bx, n, d + n, d_feat);
-    balance.resize((size_t)n);
-    if (features) features->resize((size_t)8 * n);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(balance.data(), d + n, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && features) e = hipMemcpyAsync(features->data(), d_feat, (size_t)8 * n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    SRT_HIP(ctx, hipMalloc((void**)&d, words * sizeof(uint32_t)));
+    hipError_t e = hipMemsetAsync(d, 0, words * sizeof(uint32_t), ctx->stream);
+    K.wg_cost = d;
+    const dim3 grid((unsigned)bx, (unsigned)by, 1), block(srt::WG_THREADS);
+    if (e == hipSuccess) {
+        const bool in_lds = ctx->scene_in_lds[img];
+        if (K.n_tris > 0 && in_lds) hipLaunchKernelGGL((srt::pathtrace_kernel<4, true, true, false, false, true>), grid, block, lds_bytes, ctx->stream, K);
+        else if (K.n_tris > 0) hipLaunchKernelGGL((srt::pathtrace_kernel<4, true, false, false, false, true>), grid, block, lds_bytes, ctx->stream, K);
+        else if (in_lds) hipLaunchKernelGGL((srt::pathtrace_kernel<4, false, true, false, false, true>), grid, block, lds_bytes, ctx->stream, K);
+        else hipLaunchKernelGGL((srt::pathtrace_kernel<4, false, false, false, false, true>), grid, block, lds_bytes, ctx->stream, K);
+        e = hipGetLastError();
+    }
+    counts.resize(words);
+    if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), d, words * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
-    if (e != hipSuccess) return fail(ctx, SRT_ERR_HIP, "block probe: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(ctx, SRT_ERR_HIP, "balance probe: %s", hipGetErrorString(e));
     return SRT_OK;
+}
+
+// What a block costs, from its counts: the weights are wave instructions per trip of the loop counted (a pool step costs its fixed
+// part plus the uniform-sphere groups, cluster bounds and boxes every step runs through), fitted on measured band times of
+// configs 3 and 5, Scene3, Scene_indirect and config 4's scene (tools/band_fit.py, profiles/r03/band_fit*.txt).
+struct ProbeWeights {
+    // a pool step: its fixed part + what every step runs through per group of four uniform spheres / cluster bound / box / mesh root test
+    double step = 700.0, step_ugroup = 70.0, step_cluster = 12.0, step_box = 45.0, step_mesh = 60.0;
+    double group = 660.0;          // four clustered spheres through the exact test for 64 items (carries the scatter, shuffles and merge of its round)
+    double node_round = 24.0, leaf_trip = 1915.0, mesh_phase = 63.0;  // BVH traversal (the leaf trips carry the memory round trips of the whole phase)
+    double wave = 5830.0;          // per tile: staging, primary rays, ring — what every sample chunk of a real launch repeats
+    double untraced_wave = 358.0;  // a tile with sample-independent pixels folds their colour sample by sample
+};
+static double probe_block_cost(const uint32_t* c, const srt::KernelParams& K, const ProbeWeights& w) {
+    const double step = w.step + w.step_ugroup * ((K.nu + 3) / 4) + w.step_cluster * K.nc + w.step_box * K.nb + (K.n_tris > 0 ? w.step_mesh : 0.0);
+    return step * c[srt::TALLY_STEPS] + w.group * c[srt::TALLY_GROUPS] + w.node_round * c[srt::TALLY_NODE_ROUNDS] + w.leaf_trip * c[srt::TALLY_LEAF_TRIPS] +
+           w.mesh_phase * c[srt::TALLY_MESH_PHASES] + w.wave * c[srt::TALLY_WAVES] + w.untraced_wave * c[srt::TALLY_UNTRACED_WAVES];
 }
 
 int srt_estimate_row_costs(srt_context* ctx, int max_bounces, uint32_t seed, float* row_costs) {
@@ -1022,15 +1057,22 @@ int srt_estimate_row_costs(srt_context* ctx, int max_bounces, uint32_t seed, flo
     if (!ctx->camera.set) return fail(ctx, SRT_ERR_STATE, "srt_estimate_row_costs: srt_set_camera has not been called");
     if (max_bounces < 0) return fail(ctx, SRT_ERR_INVALID_ARG, "srt_estimate_row_costs: max_bounces must be >= 0");
     const int H = ctx->height;
-    std::vector<uint32_t> h;
+    std::vector<uint32_t> counts;
     int bx = 0, by = 0;
-    const int rc = run_block_probe(ctx, max_bounces, seed, h, nullptr, bx, by);
+    const int rc = run_pool_probe(ctx, max_bounces, seed, counts, bx, by);
     if (rc != SRT_OK) return rc;
+    srt_render_params p{};
+    p.row_begin = 0, p.row_end = H, p.first_sample = 1, p.sample_count = 1, p.max_bounces = max_bounces;
+    srt::KernelParams K;
+    size_t lds_bytes = 0;
+    int use = 0, img = 0;
+    fill_kernel_params(ctx, &p, K, lds_bytes, use, img);
+    const ProbeWeights w;
     // a block covers WG_H scene rows; its cost is spread evenly over them; memory row m = scene row H - 1 - m
     for (int m = 0; m < H; ++m) row_costs[m] = 0.0f;
     for (int j = 0; j < by; ++j) {
         double sum = 0;
-        for (int i = 0; i < bx; ++i) sum += (double)h[(size_t)j * bx + i];
+        for (int i = 0; i < bx; ++i) sum += probe_block_cost(&counts[((size_t)j * bx + i) * srt::TALLY_N], K, w);
         const int y0 = j * srt::WG_H, y1 = y0 + srt::WG_H < H ? y0 + srt::WG_H : H;
         for (int y = y0; y < y1; ++y) row_costs[H - 1 - y] = (float)(sum / (double)(y1 - y0));
     }
@@ -1038,14 +1080,16 @@ int srt_estimate_row_costs(srt_context* ctx, int max_bounces, uint32_t seed, flo
 }
 
 #ifdef SRT_DEV
-// development aid (tools/band_fit.py): the probe's raw per-block sums — out[8 * (bx * by)], block (i, j) covers scene rows
-// [16 j, 16 j + 16): {probe pixels, traced, bounce rays, cluster candidates, mesh-traversal rays, misses, mesh hits, 0}
-int srt_debug_block_features(srt_context* ctx, int max_bounces, uint32_t seed, uint32_t* out, int* blocks_x, int* blocks_y) {
-    if (!ctx || !out || !blocks_x || !blocks_y) return SRT_ERR_INVALID_ARG;
-    std::vector<uint32_t> bal, feat;
-    const int rc = run_block_probe(ctx, max_bounces, seed, bal, &feat, *blocks_x, *blocks_y);
+// development aid (tools/band_fit.py): the balance probe's raw counts — out[TALLY_N * (bx * by)], block (i, j) covers scene rows
+// [16 j, 16 j + 16) — and the scene constants a step's cost depends on: consts = {uniform sphere groups, clusters, boxes, triangles}
+int srt_debug_probe_counts(srt_context* ctx, int max_bounces, uint32_t seed, uint32_t* out, int* blocks_x, int* blocks_y, int* consts4) {
+    if (!ctx || !out || !blocks_x || !blocks_y || !consts4) return SRT_ERR_INVALID_ARG;
+    std::vector<uint32_t> counts;
+    const int rc = run_pool_probe(ctx, max_bounces, seed, counts, *blocks_x, *blocks_y);
     if (rc != SRT_OK) return rc;
-    memcpy(out, feat.data(), feat.size() * sizeof(uint32_t));
+    memcpy(out, counts.data(), counts.size() * sizeof(uint32_t));
+    const srt::SceneLayout& SL = ctx->layout[0];
+    consts4[0] = (SL.nu + 3) / 4, consts4[1] = SL.nc, consts4[2] = SL.nb, consts4[3] = ctx->mesh_image.n_tris;
     return SRT_OK;
 }
 #endif

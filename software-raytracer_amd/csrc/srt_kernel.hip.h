@@ -242,14 +242,36 @@ __device__ __forceinline__ V3 ibox_normal(const BoxRay& br, V3 t1) {
     return v3((br.sgn.x * -1) * s1.x * s2.x, (br.sgn.y * -1) * s1.y * s2.y, (br.sgn.z * -1) * s1.z * s2.z);
 }
 
+// The balance probe (PROBE instantiation of pathtrace_kernel, srt_estimate_row_costs): wave-uniform counts of what the loops of
+// the path pool and of closest_hit do for a tile — the trip counts the kernel's instruction count (and, for meshes, its memory
+// round trips) follow from.  The host weighs them (srt_capi.hip, ProbeWeights).  Every other instantiation gets the empty
+// Tally: no code.  (Also counted in round 3 and dropped, their fitted weights came out at nothing: second halves of the sphere
+// test, trips of the scatter loop, fold iterations, boxes with a valid hit, steps with an environment lookup, traced and
+// untraced pixels.)
+enum {
+    TALLY_STEPS = 0,       // pool steps (one closest_hit call of the whole wave each)
+    TALLY_GROUPS,          // groups of four clustered spheres put through the exact test (a round of 64 items: K / 4)
+    TALLY_NODE_ROUNDS,     // mesh traversal: node rounds
+    TALLY_LEAF_TRIPS,      // mesh traversal: triangle trips of the leaf rounds
+    TALLY_MESH_PHASES,     // mesh traversal: phases started
+    TALLY_WAVES,           // waves (each stages the scene and traces its pixels' primary rays — once per sample chunk in a real launch)
+    TALLY_UNTRACED_WAVES,  // waves with an untraced pixel (the sample-independent colour is folded sample by sample, once per wave)
+    TALLY_N = 8
+};
+template <bool ON>
+struct Tally {
+    __device__ __forceinline__ void add(int, unsigned) {}
+};
+template <>
+struct Tally<true> {
+    unsigned c[TALLY_N];
+    __device__ __forceinline__ void add(int i, unsigned v) { c[i] += v; }
+};
+
 struct Hit {
     float t;   // distance of the recorded hit
     int prim;  // primitive id, -1 = miss (rayHit.valid == false)
     V3 n, p;   // normal, point (valid when prim >= 0)
-    // what the ray cost (read by block_cost_kernel only; dead code elsewhere): clusters whose exact spheres were tested for
-    // it, and whether it went through the mesh traversal
-    int cand;
-    bool mesh_go;
 };
 
 // ---- (distance, list index, primitive) packed so that unsigned 64-bit order == the
@@ -284,12 +306,10 @@ __device__ __forceinline__ void hit_unkey(unsigned long long k, float& t, int& p
 //      fetch the ray with __shfl, run the EXACT sphere arithmetic and merge through a 64-bit
 //      LDS atomicMin on hit_key — so the wave does sum(pairs)/64 rounds, not max-per-lane.
 //   3. boxes: every lane, exact arithmetic.
-template <bool MESH>
-__device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, V3 o, V3 d, bool active, int defer_min, bool& deferred SRT_PROF_PARAM) {
+template <bool MESH, bool PROBE = false>
+__device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, V3 o, V3 d, bool active, int defer_min, bool& deferred, Tally<PROBE>& tally SRT_PROF_PARAM) {
     float best = __builtin_inff();
     int bp = -1;
-    int n_cand = 0;
-    bool mesh_went = false;
     // exact sphere test of ray (ro, rd) against four spheres; updates (tb, pb) with the tie rule.
     // Part 1 (always): the cheap candidate test d2 <= r*r.  Part 2 (sqrt, compare) runs under
     // ONE wave-uniform branch per group and one more per sphere, so a group nobody can hit
@@ -371,7 +391,6 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                 if (lhs <= rhs) mask |= 1ull << k;
             }
             if (!active) mask = 0ull;
-            n_cand = __builtin_popcountll(mask);
             const int K4 = S.K >> 2;
             // exclusive prefix sum of popcount(mask) over the wave: one DPP scan (six adds; seven ballot slices before)
             const int cnt = __builtin_popcountll(mask);
@@ -411,6 +430,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                     V3 rd = v3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
                     float tb = __builtin_inff();
                     int pb = -1;
+                    tally.add(TALLY_GROUPS, (unsigned)K4);
                     for (int i = 0; i < K4; ++i) {
                         const int p = S.nu4 + (k * K4 + i) * 4;  // per-lane LDS gather
                         const float4 s0 = S.v[p], s1 = S.v[p + 1], s2 = S.v[p + 2], s3 = S.v[p + 3];
@@ -426,6 +446,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                     const bool on = mask != 0ull;
                     const int k = on ? __builtin_ctzll(mask) : 0;
                     mask &= mask - 1ull;
+                    tally.add(TALLY_GROUPS, (unsigned)K4);
                     for (int i = 0; i < K4; ++i) {
                         const int p = S.nu4 + (k * K4 + i) * 4;
                         const float4 s0 = S.v[p], s1 = S.v[p + 1], s2 = S.v[p + 2], s3 = S.v[p + 3];
@@ -434,7 +455,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                 }
             }
         } else {  // some lane's direction is not unit length (degenerate lerp): brute force
-            n_cand = active ? S.nc : 0;
+            tally.add(TALLY_GROUPS, (unsigned)((S.nsT - S.nu4) >> 2));
             for (int j = S.nu4; j < S.nsT; j += 4) {
                 const float4 s0 = S.v[j], s1 = S.v[j + 1], s2 = S.v[j + 2], s3 = S.v[j + 3];
                 test4(s0, s1, s2, s3, j, o, d, active, best, bp);
@@ -540,7 +561,6 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
 #ifdef SRT_DEV  // timing experiments (results are wrong): 0x100 = no mesh phases at all, 0x200 = no triangle tests
             if (P.flags & 0x100u) go = false;
 #endif
-            mesh_went = go;
             unsigned long long pend = __builtin_amdgcn_ballot_w64(go);
             const int n_go = __builtin_popcountll(pend);
             if (n_go < defer_min && n_go != __builtin_popcountll(__builtin_amdgcn_ballot_w64(active))) {
@@ -550,6 +570,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                 deferred = false;
             }
             if (pend != 0ull) {
+                tally.add(TALLY_MESH_PHASES, 1u);
                 const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
                 unsigned* qn = S.meshq;               // node item i at qn[i]
                 unsigned* qlt = S.meshq + MESH_Q - 1;  // leaf item i at qlt[-i]: both queues share the buffer's free middle
@@ -606,6 +627,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                         st_rounds += 1;
 #endif
                         if (node_round) {
+                            tally.add(TALLY_NODE_ROUNDS, 1u);
                             int logP = 3, takeN = 1;
                             if (!strict) {
                                 logP = nN <= 8 ? 3 : nN <= 16 ? 2 : nN <= 32 ? 1 : 0;
@@ -747,6 +769,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                             const int logL = nL <= 16 ? 2 : nL <= 32 ? 1 : 0;
                             const int takeL = nL < (64 >> logL) ? nL : (64 >> logL);
                             const int trips = 4 >> logL;
+                            tally.add(TALLY_LEAF_TRIPS, (unsigned)trips);
                             nL -= takeL;  // the items [nL, nL + takeL) are popped
 #ifdef SRT_STATS
                             if (SRT_STATS == 1) {
@@ -842,8 +865,6 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
     }
     h.t = best;
     h.prim = bp;
-    h.cand = n_cand;
-    h.mesh_go = mesh_went;
     h.p = v3(o.x + d.x * best, o.y + d.y * best, o.z + d.z * best);  // Object.hpp:136 / :229
     if (MESH && btri >= 0) {
         V3 n = normalized(tri_n);  // unit geometric normal, e1 x e2
@@ -969,9 +990,13 @@ __device__ __forceinline__ Lds make_lds(const KernelParams& P, float4* lds, int 
 // counts, where one workgroup per tile for ALL samples would leave too few, too long workgroups.  The
 // running mean is order-dependent (Raytracer.cpp:67), so chunks cannot fold on their own: the owner lanes
 // store the colours, in sample order, as coalesced rows of P.sample_rows and fold_kernel does the fold.
-template <int MIN_WAVES, bool MESH, bool SCENE_LDS = true, bool MULTI = false, bool DEFER = false>
+// PROBE: the balance probe of srt_estimate_row_costs — the same pool over the frame's first few samples, nothing read from or
+// written to the frame; instead every wave adds its Tally to the TALLY_N words of its block in P.wg_cost.
+template <int MIN_WAVES, bool MESH, bool SCENE_LDS = true, bool MULTI = false, bool DEFER = false, bool PROBE = false>
 __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const KernelParams P) {
+    static_assert(!PROBE || (!MULTI && !DEFER), "the probe runs the full-tile pool");
     extern __shared__ float4 lds_scene[];
+    Tally<PROBE> tally{};
 #if defined(SRT_STATS) && SRT_STATS == 3
     Prof prof;
     prof.last = (long long)__builtin_readcyclecounter();
@@ -982,6 +1007,10 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         __syncthreads();
     }
     const Lds S = make_lds<SCENE_LDS>(P, lds_scene, WG_TILES_X * WG_TILES_Y, threadIdx.x >> 6);
+    // the probe: ONE of the workgroup's four waves — the four hold the same mix of pixels (dealt pixel by pixel, see below), so a
+    // quarter of the pixels stands for the block, and the samples go into depth instead: a pool that runs 8 samples per pixel has
+    // 12..37 % more steps per sample than a launch's chunks of 32 and more (the tail of a tile), unevenly over the frame
+    if (PROBE && (threadIdx.x >> 6) != 0) return;
 
     // ---- pixel of this lane ----------------------------------------------------------
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1001,7 +1030,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     // block costs are timed with s_memrealtime, the constant 100 MHz clock all XCDs share — NOT with s_memtime
     // (__builtin_readcyclecounter): that one is a per-XCD shader-clock counter (tools/timer_probe.py: the eight XCDs' values lie
     // 4e10 .. 1.8e11 ticks apart), and a difference of two of its readings was seen to come out negative on some boxes
-    const long long t_start = P.wg_cost ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+    const long long t_start = !PROBE && P.wg_cost ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 #endif
     uint32_t block_id = blockIdx.y * gridDim.x + blockIdx.x;
     if (P.wg_order) block_id = P.wg_order[block_id];
@@ -1127,7 +1156,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
 
     // ---- primary hit: identical for every sample ------------------------------------
     bool parked = false;  // path pool: this lane's ray waits for a mesh phase (see closest_hit)
-    const Hit h0 = closest_hit<MESH>(S, P, cam, dir0, true, 1, parked SRT_PROF_ARG);
+    const Hit h0 = closest_hit<MESH>(S, P, cam, dir0, true, 1, parked, tally SRT_PROF_ARG);
 
     const bool reset = (P.flags & 1u) != 0;
     // samples of this workgroup: all of them, or chunk blockIdx.z of the launch
@@ -1146,7 +1175,11 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     const bool pix_traced = in_range && h0.prim >= 0 && B > 0 && !preview;  // (the same for every pixel of a block)
     const bool traced = pix_traced && is_leader;
     float4 untraced_val = make_float4(0, 0, 0, 0);
-    if (in_range && !pix_traced && (!DEFER || blockIdx.z == 0)) {  // (chunked: once, by the first chunk, for all samples)
+    if constexpr (PROBE) {
+        tally.add(TALLY_UNTRACED_WAVES, __builtin_amdgcn_ballot_w64(in_range && !pix_traced) != 0ull ? 1u : 0u);
+        tally.add(TALLY_WAVES, 1u);
+    }
+    if (!PROBE && in_range && !pix_traced && (!DEFER || blockIdx.z == 0)) {  // (chunked: once, by the first chunk, for all samples)
         RGB c;
         if (h0.prim < 0) {
             c = environment(S, dir0);
@@ -1420,6 +1453,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 SRT_STAT(6, n_hit);
             }
 #endif
+            tally.add(TALLY_STEPS, 1u);
             // ---- one bounce for every busy lane
             V3 o = v3(0, 0, 0);
             const float ofs = .00001f;
@@ -1448,7 +1482,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 o = v3(hp.x + hn.x * ofs, hp.y + hn.y * ofs, hp.z + hn.z * ofs);  // :177
             }
             // the scan runs in wave-uniform control flow: idle lanes help with other lanes' rays
-            const Hit h = closest_hit<MESH>(S, P, o, sray, busy, P.mesh_defer, parked SRT_PROF_ARG);
+            const Hit h = closest_hit<MESH>(S, P, o, sray, busy, P.mesh_defer, parked, tally SRT_PROF_ARG);
             if (busy && !(MESH && parked)) {
                 ++rays;
                 bool end_path;
@@ -1486,7 +1520,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         } else if (MULTI && bgrid) {
             const int oy = (int)(own_pixel / (uint32_t)W), ox = (int)(own_pixel - (uint32_t)oy * (uint32_t)W);
             write_blocks(owner, ox, oy, acc, bgrid_keep);
-        } else if (!DEFER && owner) {
+        } else if (!DEFER && !PROBE && owner) {
             write_pixel(own_pixel, acc);
         }
     }
@@ -1511,6 +1545,12 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         }
     }
 #endif
+    if constexpr (PROBE) {
+        if (lane == 0)
+            for (int i = 0; i < TALLY_N; ++i)
+                if (tally.c[i]) atomicAdd(&P.wg_cost[(size_t)block_id * TALLY_N + i], tally.c[i]);
+        return;
+    }
     if ((P.flags & 2u) || P.wg_cost) {  // SRT_RENDER_COUNT_RAYS / cost feedback for the dispatch order
         unsigned long long tot = rays;
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
@@ -1594,7 +1634,8 @@ __global__ void __launch_bounds__(64) pick_kernel(const KernelParams P, int px, 
 #if defined(SRT_STATS) && SRT_STATS == 3
     Prof prof{};
 #endif
-    const Hit h = closest_hit<true>(S, P, v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]), dir, true, 1, deferred SRT_PROF_ARG);
+    Tally<false> no_tally;
+    const Hit h = closest_hit<true>(S, P, v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]), dir, true, 1, deferred, no_tally SRT_PROF_ARG);
     if (threadIdx.x == 0) {
         out_index[0] = h.prim >= 0 ? S.order(h.prim) : -1;
         out_index[1] = __float_as_int(h.t);
@@ -1612,16 +1653,10 @@ __global__ void __launch_bounds__(64) pick_kernel(const KernelParams P, int px, 
 // (measured: ordering by primary hits left the first launch of config 4 13 % and of Scene3 10 % behind the
 // learned order).  Any order gives the same image.
 constexpr int ORDER_BUCKETS = 16, ORDER_SORT_THREADS = 512;
-// Balance cost (srt_estimate_row_costs): TIME a block's pixels will take per sample, in 1/64 of the time of one analytic bounce
-// ray that meets no cluster.  Weights from least squares on measured band times of configs 3 and 5 — the bands an 8-rank run
-// launches (equal split, the same shifted by half a band) and the bands of the balanced 2- / 4- / 8-way splits themselves, with a
-// constant per launch in the model (tools/band_fit.py): a sample of a pixel that traces nothing costs next to
-// nothing (the constant had been hiding in this weight: 7 before), a bounce ray 64, every cluster whose spheres are tested
-// exactly for it 14, a ray that goes through the mesh traversal about sixteen analytic rays.  Whether a ray ENDS on a mesh adds
-// nothing once the traversal is counted (fitted weight 0).
-constexpr unsigned BAL_W_PIXEL = 2u, BAL_W_RAY = 64u, BAL_W_CAND = 14u, BAL_W_MESH_GO = 1000u, BAL_W_MESH_HIT = 0u;
+// (Rounds 2-3 also derived the multi-GPU balance cost here, from these 16 paths per block; since round 3 that is the job of the
+// PROBE instantiation of pathtrace_kernel, which runs the real pool — see Tally.)
 template <bool SCENE_LDS>
-__global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, uint32_t* cost, int blocks_x, int n_blocks, uint32_t* balance_cost, uint32_t* features) {
+__global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, uint32_t* cost, int blocks_x, int n_blocks) {
     extern __shared__ float4 lds_scene[];
     if constexpr (SCENE_LDS) {
         for (int i = threadIdx.x; i < P.scene_vec4; i += 64) lds_scene[i] = P.scene[i];
@@ -1643,15 +1678,10 @@ __global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, ui
 #if defined(SRT_STATS) && SRT_STATS == 3
     Prof prof{};
 #endif
-    Hit h = closest_hit<true>(S, P, v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]), sray, in_range, 1, deferred SRT_PROF_ARG);
+    Tally<false> no_tally;
+    Hit h = closest_hit<true>(S, P, v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]), sray, in_range, 1, deferred, no_tally SRT_PROF_ARG);
     const int first_mesh_prim = S.nsT + S.nb;
     unsigned c = in_range ? 1u : 0u;
-    // second estimate, for splitting a frame over GPUs (srt_estimate_row_costs): TIME rather than rays, in 1/64 of the time
-    // of one bounce ray — a sample of a pixel that traces nothing costs about 0.11 of that (the running mean is still
-    // evaluated sample by sample), the primary ray is traced once per pixel whatever the sample count (free), a bounce ray
-    // that ends on a mesh about six times an analytic one (fitted to measured bands of configs 3 and 5)
-    unsigned cb = in_range ? BAL_W_PIXEL : 0u;
-    unsigned f_traced = 0u, f_rays = 0u, f_cand = 0u, f_go = 0u, f_miss = 0u, f_meshhit = 0u;  // (fitting aid, see `features`)
     bool alive = in_range && h.prim >= 0 && P.max_bounces > 0 && !(P.flags & 4u);
     uint32_t rng = srt_rng_key(P.seed, (uint32_t)(x + y * P.width), P.first_sample);
     float spec = 0.0f;
@@ -1659,7 +1689,6 @@ __global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, ui
         spec = (S.mat(h.prim, 0).y >= rand_unit(srt_mix32(rng) >> 17)) ? 1.0f : 0.0f;
         rng += 0x9E3779B9U;
         c += h.prim >= first_mesh_prim ? (SRT_MESH_ORDER_W - 1u) : 0u;
-        f_traced = 1u;
     }
     for (int bounce = 0; bounce < P.max_bounces && __builtin_amdgcn_ballot_w64(alive) != 0ull; ++bounce) {
         V3 o = v3(0, 0, 0);
@@ -1675,11 +1704,9 @@ __global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, ui
             sray = normalized(v3(sr.x * (1 - tt) + refl.x * tt, sr.y * (1 - tt) + refl.y * tt, sr.z * (1 - tt) + refl.z * tt));
             o = v3(h.p.x + h.n.x * .00001f, h.p.y + h.n.y * .00001f, h.p.z + h.n.z * .00001f);
         }
-        const Hit g = closest_hit<true>(S, P, o, sray, alive, 1, deferred SRT_PROF_ARG);
+        const Hit g = closest_hit<true>(S, P, o, sray, alive, 1, deferred, no_tally SRT_PROF_ARG);
         if (alive) {
             c += g.prim >= first_mesh_prim ? SRT_MESH_ORDER_W : 1u;
-            cb += BAL_W_RAY + BAL_W_CAND * (unsigned)g.cand + (g.mesh_go ? BAL_W_MESH_GO : 0u) + (g.prim >= first_mesh_prim ? BAL_W_MESH_HIT : 0u);
-            f_rays += 1u, f_cand += (unsigned)g.cand, f_go += g.mesh_go ? 1u : 0u, f_miss += g.prim < 0 ? 1u : 0u, f_meshhit += g.prim >= first_mesh_prim ? 1u : 0u;
             if (g.prim < 0) {
                 alive = false;
             } else {
@@ -1689,18 +1716,8 @@ __global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, ui
             }
         }
     }
-    for (int off = 8; off > 0; off >>= 1) c += __shfl_down(c, off, 16), cb += __shfl_down(cb, off, 16);
-    if (k == 0 && block < n_blocks) {
-        cost[block] = c;
-        if (balance_cost) balance_cost[block] = cb;
-    }
-    if (features) {  // development aid (tools/band_fit.py): the raw sums the balance weights are fitted on, 8 words per block
-        unsigned f[8] = {in_range ? 1u : 0u, f_traced, f_rays, f_cand, f_go, f_miss, f_meshhit, 0u};
-        for (int i = 0; i < 7; ++i) {
-            for (int off = 8; off > 0; off >>= 1) f[i] += __shfl_down(f[i], off, 16);
-            if (k == 0 && block < n_blocks) features[(size_t)block * 8 + i] = f[i];
-        }
-    }
+    for (int off = 8; off > 0; off >>= 1) c += __shfl_down(c, off, 16);
+    if (k == 0 && block < n_blocks) cost[block] = c;
 }
 
 // The probe estimate is 16 one-sample paths per block: noisy.  Costs vary smoothly over the image except at object

@@ -195,11 +195,11 @@ void MultiGpuRenderer::BalanceBands() {
     for (int i = 0; i < height_; ++i) prefix[(size_t)i + 1] = prefix[(size_t)i] + (cost[(size_t)i] > 0 ? cost[(size_t)i] : 0.0);
     const double total = prefix[(size_t)height_];
     bounds_[0] = 0;
-    for (int k = 1; k < n; ++k) {  // first row whose prefix cost reaches k/n of the total, rounded to 8 rows, every band >= 1 row
+    for (int k = 1; k < n; ++k) {  // first row whose prefix cost reaches k/n of the total, rounded to 2 rows, every band >= 1 row
         const int lo = bounds_[(size_t)k - 1] + 1, hi = height_ - (n - k);
         int i = lo;
         while (i < hi && prefix[(size_t)i] < total * k / n) ++i;
-        const int j = ((i + 4) / 8) * 8;
+        const int j = ((i + 1) / 2) * 2;
         if (j >= lo && j <= hi) i = j;
         bounds_[(size_t)k] = i < lo ? lo : (i > hi ? hi : i);
     }

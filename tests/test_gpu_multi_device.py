@@ -84,6 +84,49 @@ def test_balanced_bands_equal_the_single_device_frame(srt):
     pt.close()
 
 
+def test_balance_probe_leaves_the_frame_alone(srt, oracle):
+    """srt_estimate_row_costs runs the PROBE instantiation of the path-trace kernel (the real pool, loop trips counted): it
+    must not touch accumulator, framebuffer, ray count or the accumulation state — a frame rendered around a probe equals
+    the frame rendered without one — and must work for every instantiation: analytic, mesh, scene image beyond LDS."""
+    import ctypes as C
+    w, h = 320, 180
+    objs = oracle.load_scene_json_py(scene_path("Scene1"))
+    big = objs[64]
+    mesh_objs = list(objs)
+    mesh_objs[64] = dict(type=oracle.OBJ_MESH, position=big["position"], mesh=0, base=big["base"], emissive=big["emissive"],
+                         smoothness=big["smoothness"], specular_amount=big["specular_amount"], specular=big["specular"])
+    V, T = oracle.uv_sphere(1.0, 24, 32)
+    marr, mn, keep = oracle.make_meshes([(V, T)])
+    rng = np.random.default_rng(5)
+    many = [dict(type=oracle.OBJ_SPHERE, position=(0, -1001, 5), radius=1000, base=(.8, .8, .8))]
+    for _ in range(3400):
+        many.append(dict(type=oracle.OBJ_SPHERE, position=(float(rng.uniform(-6, 6)), float(rng.uniform(-0.8, 3)), float(rng.uniform(3, 14))),
+                         radius=float(rng.uniform(0.03, 0.12)), base=tuple(float(v) for v in rng.uniform(0.2, 1, 3))))
+    for name, scene_objs, meshes in (("analytic", objs, None), ("mesh", mesh_objs, (marr, mn)), ("beyond LDS", many, None)):
+        oarr, n = oracle.make_objects(scene_objs)
+        pt = srt.PathTracer(w, h)
+        if meshes:
+            pt.set_meshes(C.cast(meshes[0], C.POINTER(srt.Mesh)), meshes[1])
+        pt.set_scene(C.cast(oarr, C.POINTER(srt.Object)), n)
+        pt.set_camera(srt.default_camera())
+        pt.render(spp=3, bounces=6, seed=1, count_rays=True)
+        acc, fb, rays = pt.accumulator().copy(), pt.framebuffer().copy(), pt.stats().rays
+        c1 = pt.estimate_row_costs(6, 1)
+        assert len(c1) == h and min(c1) > 0 and c1 == pt.estimate_row_costs(6, 1), name
+        assert np.array_equal(pt.accumulator().view(np.uint32), acc.view(np.uint32)) and np.array_equal(pt.framebuffer(), fb), name
+        assert pt.stats().rays == rays, name
+        pt.render(spp=2, bounces=6, seed=1, first_sample=4, reset=False)  # the accumulation goes on as if nothing had happened
+        ref = srt.PathTracer(w, h)
+        if meshes:
+            ref.set_meshes(C.cast(meshes[0], C.POINTER(srt.Mesh)), meshes[1])
+        ref.set_scene(C.cast(oarr, C.POINTER(srt.Object)), n)
+        ref.set_camera(srt.default_camera())
+        ref.render(spp=5, bounces=6, seed=1)
+        assert np.array_equal(pt.accumulator().view(np.uint32), ref.accumulator().view(np.uint32)), name
+        pt.close()
+        ref.close()
+
+
 def test_gather_band_argument_checks(srt):
     a, b, c = srt.PathTracer(64, 32), srt.PathTracer(64, 32), srt.PathTracer(32, 32)
     with pytest.raises(srt.SrtError):

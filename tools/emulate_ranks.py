@@ -12,6 +12,8 @@ ap.add_argument("config", type=int, choices=[3, 5])
 ap.add_argument("--ranks", default="2,4,8")
 ap.add_argument("--modes", default="probe,equal")
 ap.add_argument("--json", default="")
+ap.add_argument("--align", type=int, default=2, help="row alignment of the cost-balanced split")
+ap.add_argument("--weights", default="", help="development: JSON of probe weights; the split is then computed here from the raw counts (development library)")
 a = ap.parse_args()
 CFG = {3: ("Scene1", 0, 1920, 1080, 512, 8), 5: ("Scene1", 224, 3840, 2160, 1024, 16)}
 scene, mesh, W, H, spp, bounces = CFG[a.config]
@@ -44,15 +46,39 @@ def band_ms(rows):
     return statistics.median(ts[3:])
 
 
-pt = tracer()
-row_cost = pt.estimate_row_costs(bounces, 0)
-pt.close()
+TALLY = ["steps", "groups", "node_rounds", "leaf_trips", "mesh_phases", "waves", "untraced_waves", "_"]  # srt::TALLY_*
+probe_rows = consts = None
+if a.weights:
+    import ctypes as C
+    dev = srt.capi.open_library(os.path.join(ROOT, "software-raytracer_amd", "libsrt_pathtrace_dev.so"))
+    dev.srt_debug_probe_counts.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    pd = srt.PathTracer(W, H, lib=dev)
+    pd.set_meshes(meshes, nm); pd.set_scene(objs, n); pd.set_camera(srt.default_camera())
+    nb = ((W + 15) // 16) * ((H + 15) // 16)
+    NT = len(TALLY)
+    buf = (C.c_uint32 * (NT * nb))(); bx, by = C.c_int(0), C.c_int(0); cc = (C.c_int * 4)()
+    assert dev.srt_debug_probe_counts(pd._h, bounces, 0, buf, C.byref(bx), C.byref(by), cc) == 0
+    pd.close()
+    probe_rows = [[sum(buf[NT * (j * bx.value + i) + f] for i in range(bx.value)) for f in range(NT)] for j in range(by.value)]
+    consts = list(cc)
+    wt = json.loads(a.weights)
+    stepw = wt.get("step", 700.0) + wt.get("step_ugroup", 70.0) * consts[0] + wt.get("step_cluster", 12.0) * consts[1] + wt.get("step_box", 45.0) * consts[2] + (wt.get("step_mesh", 60.0) if consts[3] else 0.0)
+    row_cost = [0.0] * H
+    for j, row in enumerate(probe_rows):
+        c = stepw * row[0] + sum(v * row[TALLY.index(k)] for k, v in wt.items() if k in TALLY)
+        y0, y1 = 16 * j, min(16 * j + 16, H)
+        for y in range(y0, y1):
+            row_cost[H - 1 - y] = c / (y1 - y0)
+else:
+    pt = tracer()
+    row_cost = pt.estimate_row_costs(bounces, 0)
+    pt.close()
 whole = band_ms((0, H))
 print("config %d: whole frame on one GPU %.2f ms" % (a.config, whole), flush=True)
-doc = {"config": a.config, "whole_frame_ms": whole, "splits": []}
+doc = {"config": a.config, "whole_frame_ms": whole, "splits": [], "probe_rows": probe_rows, "consts": consts, "height": H}
 for N in (int(v) for v in a.ranks.split(",")):
     for mode in a.modes.split(","):
-        bands = stripes.partition_rows(H, N, row_cost if mode == "probe" else None, align=8 if mode == "probe" else 1)
+        bands = stripes.partition_rows(H, N, row_cost if mode == "probe" else None, align=a.align if mode == "probe" else 1)
         ms = [band_ms(b) for b in bands]
         eff = sum(ms) / N / max(ms)
         print("config %d N=%d %-5s rows %s\n      ms %s | slowest %.2f  mean/slowest %.3f  (whole/N)/slowest %.3f" %
