@@ -225,12 +225,22 @@ int srt_write_accumulator(srt_context* ctx, const float* src_rgba);
  * software-raytracer_amd/stripes.py, bench.py --gpus N.) */
 int srt_gather_band(srt_context* dst, srt_context* src, int row_begin, int row_end);
 /* Relative cost of every MEMORY row of the frame for the current scene and camera (row_costs[height], arbitrary
- * units), from a device-side probe: 1/16 of the pixels, one sample each, the same paths the renderer would trace
- * (about 0.1 ms at 1080p).  Deterministic — every process of a multi-GPU job computes the same numbers, so the ranks
- * can agree on cost-balanced row bands without talking to each other.  The reference's static split into 16 equal
- * column stripes (Raytracer.cpp:330-342) leaves its workers idle behind the slowest one; equal ROW bands are worse
- * (sky rows cost a tenth of floor rows).  Synchronous. */
+ * units), from a device-side probe: the path-trace kernel's own path pool, run over a quarter of the pixels for the
+ * frame's first 32 samples, COUNTING what its loops do (pool steps, exactly tested sphere groups, BVH rounds, per-tile
+ * work) instead of writing the frame; the counts are weighed into a cost.  Nothing of the frame is read or written.
+ * About 2 % of a 512-spp launch.  Counts, not times: deterministic — every process of a multi-GPU job computes the
+ * same numbers, so the ranks can agree on cost-balanced row bands without talking to each other.  The reference's
+ * static split into 16 equal column stripes (Raytracer.cpp:330-342) leaves its workers idle behind the slowest one;
+ * equal ROW bands are worse (sky rows cost a tenth of floor rows).  Synchronous. */
 int srt_estimate_row_costs(srt_context* ctx, int max_bounces, uint32_t seed, float* row_costs);
+
+/* ---- diagnostics ----------------------------------------------------------------- */
+/* Self-test of the kernel's shortened arithmetic (csrc/srt_kernel.hip.h: float3::Normalized, the box slab slopes and the
+ * accumulation weight 1 / frame without the rescaling and fix-up steps of the library sqrt / divide where those are
+ * identities): `vectors` pseudo-random vectors — all magnitudes, zero and denormal components, infinities, NaNs — through
+ * the short and the library path on the device, and 1 / frame for every frame up to 2^24 (vectors >= 2^24 covers them
+ * all); *mismatches = how many differ in any bit (must be 0).  Not part of the reference's interface. */
+int srt_selftest_arith(int device, uint32_t seed, uint64_t vectors, uint64_t* mismatches);
 
 #ifdef __cplusplus
 }

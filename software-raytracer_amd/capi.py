@@ -25,6 +25,7 @@ EXPORTS = [
     "srt_set_stream", "srt_bind_output", "srt_device_framebuffer", "srt_device_accumulator",
     "srt_render", "srt_wait", "srt_poll", "srt_get_stats", "srt_pick", "srt_read_framebuffer",
     "srt_read_accumulator", "srt_write_accumulator", "srt_gather_band", "srt_estimate_row_costs",
+    "srt_selftest_arith",
 ]
 
 
@@ -178,6 +179,7 @@ def open_library(path):
     L.srt_write_accumulator.argtypes = [ctx, C.POINTER(C.c_float)]
     L.srt_gather_band.argtypes = [ctx, ctx, C.c_int, C.c_int]
     L.srt_estimate_row_costs.argtypes = [ctx, C.c_int, C.c_uint32, C.POINTER(C.c_float)]
+    L.srt_selftest_arith.argtypes = [C.c_int, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name != "srt_last_error":

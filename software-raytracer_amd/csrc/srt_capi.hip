@@ -1094,6 +1094,30 @@ int srt_debug_probe_counts(srt_context* ctx, int max_bounces, uint32_t seed, uin
 }
 #endif
 
+int srt_selftest_arith(int device, uint32_t seed, uint64_t vectors, uint64_t* mismatches) {
+    if (!mismatches || vectors == 0 || vectors > (1ull << 36)) return SRT_ERR_INVALID_ARG;
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess) {
+        (void)hipGetLastError();
+        return SRT_ERR_NO_DEVICE;
+    }
+    unsigned long long* d = nullptr;
+    hipError_t e = hipMalloc((void**)&d, sizeof *d);
+    if (e == hipSuccess) e = hipMemset(d, 0, sizeof *d);
+    for (uint64_t done = 0; e == hipSuccess && done < vectors; done += 1ull << 28) {  // grids of at most 2^20 blocks
+        const uint64_t part = vectors - done < (1ull << 28) ? vectors - done : (1ull << 28);
+        hipLaunchKernelGGL(srt::selftest_normalize_kernel, dim3((unsigned)((part + 255) / 256)), dim3(256), 0, 0, seed + (uint32_t)(done >> 28) * 0x85EBCA6Bu, part, d);
+        e = hipGetLastError();
+    }
+    unsigned long long h = 0;
+    if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost);
+    if (d) (void)hipFree(d);
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) return SRT_ERR_HIP;
+    *mismatches = h;
+    return SRT_OK;
+}
+
 int srt_gather_band(srt_context* dst, srt_context* src, int row_begin, int row_end) {
     if (!dst || !src) return SRT_ERR_INVALID_ARG;
     if (dst->width != src->width || dst->height != src->height)

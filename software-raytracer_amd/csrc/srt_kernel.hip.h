@@ -173,14 +173,53 @@ __device__ __forceinline__ float rand_unit(uint32_t r) {
     return __builtin_fmaf(__builtin_fmaf(-q0, b, a), y, q0);
 }
 
+// n / d, correctly rounded, for operands INSIDE the window in which the library division's rescaling (v_div_scale) and fix-up
+// (v_div_fixup) are identities: d normal with 2^-60 <= |d| <= 2^60, and n zero, NaN or within 2^60 of d either way.  The call
+// sites guarantee the window by construction (see there); normalized() below, whose operands are arbitrary, tests it.  What
+// is left of the expansion: the reciprocal, its two-step refinement, the two-step refinement of the quotient — the same
+// operations on the same values as the library path, seven instructions instead of eleven.
+__device__ __forceinline__ float div_window(float n, float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float r1 = __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+    const float q0 = n * r1;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r1, q0);
+    return __builtin_fmaf(__builtin_fmaf(-d, q1, n), r1, q1);
+}
+
 struct V3 {
     float x, y, z;
 };
 __device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
-// float3::Normalized (Common.hpp:159-162)
-__device__ __forceinline__ V3 normalized(V3 a) {
+// float3::Normalized (Common.hpp:159-162): sqrtf and three IEEE divisions by the same length.
+// The compiler expands sqrtf into v_sqrt_f32 + the two one-ulp corrections, wrapped in a rescaling for arguments below 2^-96 and a
+// class test for 0 / inf / NaN, and EACH division into v_div_scale x 2, v_rcp_f32, the two-step refinement of the reciprocal, the
+// two-step refinement of the quotient (v_div_fmas) and v_div_fixup: 20 + 3 x 11 instructions, four of them quarter-rate.  With
+// the squared length in [2^-96, 2^96] and every component at least 2^-60 of the length (so: not zero, quotient normal) the
+// rescalings and fix-ups are identities — v_div_scale hands its operands back, v_div_fmas is a plain FMA — and what remains is the
+// chain below, with the reciprocal's refinement done once for all three quotients: the same operations on the same values, the
+// same bits.  One wave-uniform test decides; any lane outside the window (an axis-parallel ray has zero components) sends the
+// wave down the library path.  tests/test_gpu_fast_arith.py compares the two paths bit for bit on 2^28 random and edge vectors.
+__device__ __forceinline__ V3 normalized_ieee(V3 a) {
     float length = sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z);
     return v3(a.x / length, a.y / length, a.z / length);
+}
+__device__ __forceinline__ V3 normalized(V3 a) {
+    const float x = (a.x * a.x + a.y * a.y) + a.z * a.z;
+    const float s0 = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s0) - 1u), sp = __uint_as_float(__float_as_uint(s0) + 1u);
+    float len = (0.0f >= __builtin_fmaf(-sm, s0, x)) ? sm : s0;  // the expansion's corrections: one ulp down, one ulp up
+    len = (0.0f < __builtin_fmaf(-sp, s0, x)) ? sp : len;
+    const float tiny = len * 0x1p-60f;
+    const bool ok = x >= 0x1p-96f && x <= 0x1p96f && fabsf(a.x) >= tiny && fabsf(a.y) >= tiny && fabsf(a.z) >= tiny;  // (NaN: false)
+    if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) return normalized_ieee(a);
+    const float r0 = __builtin_amdgcn_rcpf(len);
+    const float r1 = __builtin_fmaf(__builtin_fmaf(-len, r0, 1.0f), r0, r0);
+    auto quot = [&](float n) {
+        const float q0 = n * r1;
+        const float q1 = __builtin_fmaf(__builtin_fmaf(-len, q0, n), r1, q0);
+        return __builtin_fmaf(__builtin_fmaf(-len, q1, n), r1, q1);
+    };
+    return v3(quot(a.x), quot(a.y), quot(a.z));
 }
 __device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 
@@ -217,7 +256,9 @@ __device__ __forceinline__ BoxRay box_ray_setup(V3 rd) {
     BoxRay b;
     b.sgn = v3(sign1(rd.x), sign1(rd.y), sign1(rd.z));
     const float eps = (float)1e-8;
-    b.m = v3(b.sgn.x / tmax(fabsf(rd.x), eps), b.sgn.y / tmax(fabsf(rd.y), eps), b.sgn.z / tmax(fabsf(rd.z), eps));
+    // (every direction that gets here comes out of normalized(): components in [-1, 1] or NaN, so the denominators lie in
+    // [1e-8, 1] — tmax turns a NaN into eps — and the numerators are +-1, +0 or NaN: inside div_window's window)
+    b.m = v3(div_window(b.sgn.x, tmax(fabsf(rd.x), eps)), div_window(b.sgn.y, tmax(fabsf(rd.y), eps)), div_window(b.sgn.z, tmax(fabsf(rd.z), eps)));
     b.am = v3(fabsf(b.m.x), fabsf(b.m.y), fabsf(b.m.z));
     return b;
 }
@@ -937,7 +978,8 @@ __device__ __forceinline__ void accumulate_sample(const KernelParams& P, float4&
         // :66  float weight = 1.0 / ACCUMULATIONFRAMES (double divide, rounded once).  For
         // frame <= 2^24 the float divide gives the same bits (1/f cannot sit within 2^-53
         // of a binary32 rounding boundary unless it is exact; checked exhaustively in tests).
-        float weight = frame <= 16777216u ? 1.0f / (float)(int)frame : (float)(1.0 / (double)(int)frame);
+        // (1 / an integer in [1, 2^24]: inside div_window's window; checked against the division for every one of them)
+        float weight = frame <= 16777216u ? div_window(1.0f, (float)(int)frame) : (float)(1.0 / (double)(int)frame);
         float om = 1 - weight;
         // :67; the accumulator may come from the caller (srt_write_accumulator): its product keeps the clamp, the rest is NN
         acc.x = clamp0(acc.x * om) + c.r * weight;
@@ -1614,6 +1656,53 @@ __global__ void __launch_bounds__(256) fold_kernel(const KernelParams P, int til
         accumulate_sample(P, acc, RGB{c.x, c.y, c.z}, s);
     }
     store_pixel(P, pixel, acc);
+}
+
+// srt_selftest_arith: vector i of the test set, normalized() against normalized_ieee(), bit for bit.  Waves 0 mod 4 draw all
+// three components from one moderate range (the short path runs), the others mix in every class of float (mostly the library
+// path, and the decision between the two is itself under test).
+__global__ void __launch_bounds__(256) selftest_normalize_kernel(uint32_t seed, unsigned long long n, unsigned long long* mismatches) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+    const unsigned wave_kind = (unsigned)((i >> 6) & 3ull);
+    uint32_t h = srt_mix32(seed ^ (uint32_t)i) + (uint32_t)(i >> 32) * 0x9E3779B9U;
+    auto next = [&]() { h = srt_mix32(h + 0x9E3779B9U); return h; };
+    auto any_float = [&](unsigned kind) {
+        const uint32_t r = next();
+        switch (kind) {
+            case 0: return __uint_as_float((r & 0x807FFFFFu) | ((100u + (next() % 56u)) << 23));   // |v| in [2^-27, 2^29)
+            case 1: return __uint_as_float(r);                                                      // any bit pattern
+            case 2: return __uint_as_float((r & 0x807FFFFFu) | ((next() % 255u) << 23));            // any finite exponent, denormals
+            default: {
+                const uint32_t pick = next() % 8u;
+                const float special[8] = {0.0f, -0.0f, 1.0f, -1.0f, __uint_as_float(0x7f800000u), __uint_as_float(0x00000001u), __uint_as_float(0x7fc00000u), 0x1p-63f};
+                return special[pick];
+            }
+        }
+    };
+    V3 a;
+    if (wave_kind == 0) {
+        const unsigned base = 40u + next() % 170u;  // one exponent per vector, components within 2^8 of each other
+        auto comp = [&]() { const uint32_t r = next(); return __uint_as_float((r & 0x807FFFFFu) | ((base + (r >> 8) % 8u) << 23)); };
+        a = v3(comp(), comp(), comp());
+    } else {
+        a = v3(any_float(next() % 4u), any_float(next() % 4u), any_float(wave_kind));
+    }
+    const V3 f = normalized(a), g = normalized_ieee(a);
+    bool same = __float_as_uint(f.x) == __float_as_uint(g.x) && __float_as_uint(f.y) == __float_as_uint(g.y) && __float_as_uint(f.z) == __float_as_uint(g.z);
+    // div_window at its two call sites: 1 / frame for every frame in [1, 2^24] (vector i checks frame i + 1), and the slab
+    // slopes of box_ray_setup for the components of a normalized direction (g: in [-1, 1] or NaN, zeros included)
+    if (i < 16777216ull) {
+        const float fr = (float)(int)(i + 1ull);
+        same = same && __float_as_uint(div_window(1.0f, fr)) == __float_as_uint(1.0f / fr);
+    }
+    const float eps = (float)1e-8;
+    const float comps[3] = {g.x, g.y, g.z};
+    for (int k = 0; k < 3; ++k) {
+        const float sg = sign1(comps[k]), dn = tmax(fabsf(comps[k]), eps);
+        const float u = div_window(sg, dn), w = sg / dn;
+        same = same && (__float_as_uint(u) == __float_as_uint(w) || (u != u && w != w));  // (a NaN slope rejects every box whatever its payload)
+    }
+    if (i < n && !same) atomicAdd(mismatches, 1ull);
 }
 
 // Picking (Raytracer.cpp:525-541): one wave, every lane traces the same ray.
