@@ -370,6 +370,8 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
     };
     auto part2 = [&](const Cand& k, int p, float& tb, int& pb) {
         if (__builtin_amdgcn_ballot_w64(k.c) != 0ull) {
+            // (the library sqrtf stays here: its short form behind a wave-uniform window test, as in normalized(), saves seven of
+            // twenty instructions but doubles the code of all 43 inlined copies — measured -2 % .. +2 %, no gain)
             float t1 = k.tc - sqrtf(k.x);  // :131-133
             // Raytracer.cpp:130-132; on an exact tie the earlier entry of ObjectsToRender wins.
             // Branch-free on purpose (see the note in the triangle phase).
@@ -1411,6 +1413,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             // (Two passes.  Tried in round 3: up to 8 passes for tiles with fewer than 16 traced pixels, 4 below 32 — every pass
             // starts at most one sample per slot, so such a tile keeps few lanes busy — but on whole frames and on the 135-row
             // bands of config 3 it was 0.4..2 % slower: the sparse tiles are too few, the longer loop costs everyone.)
+            bool fresh = false;
             for (int pass = 0; pass < 2; ++pass) {
                 const unsigned long long freem = __builtin_amdgcn_ballot_w64(!busy);
                 const uint32_t lim = count < own_done + (uint32_t)depth ? count : own_done + (uint32_t)depth;
@@ -1462,28 +1465,30 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                     __builtin_amdgcn_wave_barrier();
                     if (!busy) m = match[frank];
                 }
-                if (m != 0xFFFFFFFFu) {
+                if (m != 0xFFFFFFFFu) {  // (the sample is set up below, once for the lanes of both passes)
                     task = m;
-                    const uint32_t sidx = m >> 6;
-                    const float* r = rec + (int)(m & 63u) * 12;
-                    const int prim0 = __float_as_int(r[9]);
-                    // Raytracer.cpp:162-166 for sample sidx of that pixel
-                    rng = srt_rng_key(P.seed, __float_as_uint(r[10]), P.first_sample + s_base + sidx);
-                    uint32_t rr = srt_mix32(rng) >> 17;
-                    rng += 0x9E3779B9U;
-                    float4 m0 = S.mat(prim0, 0), m1 = S.mat(prim0, 1);
-                    spec = (m0.y >= rand_unit(rr)) ? 1.0f : 0.0f;  // :165
-                    L = RGB{m1.y, m1.z, m1.w};                                         // :162 (clamped in the image)
-                    T = RGB{m0.z, m0.w, m1.x};                                         // :163
-                    sray = v3(r[0], r[1], r[2]);                                       // :164
-                    hn = v3(r[3], r[4], r[5]);
-                    hp = v3(r[6], r[7], r[8]);
-                    hprim = prim0;
-                    bounce = 0;
                     busy = true;
-                    ++rays;  // the sample's primary GetClosestObject call (:142)
+                    fresh = true;
                 }
                 __builtin_amdgcn_wave_barrier();
+            }
+            if (fresh) {  // a lane that has just taken a task: Raytracer.cpp:162-166 for sample sidx of that pixel
+                const uint32_t sidx = task >> 6;
+                const float* r = rec + (int)(task & 63u) * 12;
+                const int prim0 = __float_as_int(r[9]);
+                rng = srt_rng_key(P.seed, __float_as_uint(r[10]), P.first_sample + s_base + sidx);
+                uint32_t rr = srt_mix32(rng) >> 17;
+                rng += 0x9E3779B9U;
+                float4 m0 = S.mat(prim0, 0), m1 = S.mat(prim0, 1);
+                spec = (m0.y >= rand_unit(rr)) ? 1.0f : 0.0f;  // :165
+                L = RGB{m1.y, m1.z, m1.w};                                         // :162 (clamped in the image)
+                T = RGB{m0.z, m0.w, m1.x};                                         // :163
+                sray = v3(r[0], r[1], r[2]);                                       // :164
+                hn = v3(r[3], r[4], r[5]);
+                hp = v3(r[6], r[7], r[8]);
+                hprim = prim0;
+                bounce = 0;
+                ++rays;  // the sample's primary GetClosestObject call (:142)
             }
 
             SRT_TICK(1);
