@@ -1297,7 +1297,8 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             r[3] = h0.n.x, r[4] = h0.n.y, r[5] = h0.n.z;
             r[6] = h0.p.x, r[7] = h0.p.y, r[8] = h0.p.z;
             r[9] = __int_as_float(h0.prim);
-            r[10] = __uint_as_float(rng_pixel);
+            // srt_rng_key's first two rounds depend on seed and pixel only: done here once, the sample's round at the hand-out
+            r[10] = __uint_as_float(srt_mix32(srt_mix32(P.seed ^ 0xA511E9B3U) + rng_pixel));
             r[11] = __uint_as_float(pixel);
         }
         constexpr int ring_depth = RING_DEPTH;
@@ -1480,7 +1481,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 const uint32_t sidx = task >> 6;
                 const float* r = rec + (int)(task & 63u) * 12;
                 const int prim0 = __float_as_int(r[9]);
-                rng = srt_rng_key(P.seed, __float_as_uint(r[10]), P.first_sample + s_base + sidx);
+                rng = srt_mix32(__float_as_uint(r[10]) + (P.first_sample + s_base + sidx));  // = srt_rng_key(seed, pixel, sample), see the record
                 uint32_t rr = srt_mix32(rng) >> 17;
                 rng += 0x9E3779B9U;
                 float4 m0 = S.mat(prim0, 0), m1 = S.mat(prim0, 1);
