@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SRT_ABI_VERSION 4
+#define SRT_ABI_VERSION 5
 
 typedef enum srt_status {
     SRT_OK = 0,

@@ -16,7 +16,7 @@ _LIB = os.path.join(_PKG, "libsrt_pathtrace.so")
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_OOM = range(6)
 OBJ_NONE, OBJ_SPHERE, OBJ_BOX, OBJ_MESH = 0, 1, 2, 3
 RENDER_RESET, RENDER_COUNT_RAYS, RENDER_PREVIEW = 1, 2, 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/srt_pathtrace.h declares (tests check the library exports them all)
 EXPORTS = [
