@@ -1051,7 +1051,24 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     for (int i = 0; i < 8; ++i) prof.acc[i] = 0;
 #endif
     if constexpr (SCENE_LDS) {  // stage the scene image into LDS (coalesced 16-byte loads)
-        for (int i = threadIdx.x; i < P.scene_vec4; i += WG_THREADS) lds_scene[i] = P.scene[i];
+        // All of a thread's rows are requested before the first one is stored: written as a plain copy loop this compiled to
+        // load - wait - store per row, five dependent L2 round trips (3..4 us) before a workgroup of Scene1 could start —
+        // 2 % of a 32-sample tile, 4 % of a 24-sample chunk, most of what an all-sky tile costs.  Eight rows per thread cover
+        // 32 KB; larger images finish in the loop.
+        constexpr int STAGE = 8;
+        const int n = P.scene_vec4;
+        float4 row[STAGE];
+#pragma unroll
+        for (int k = 0; k < STAGE; ++k) {
+            const int i = (int)threadIdx.x + k * WG_THREADS;
+            row[k] = i < n ? P.scene[i] : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < STAGE; ++k) {
+            const int i = (int)threadIdx.x + k * WG_THREADS;
+            if (i < n) lds_scene[i] = row[k];
+        }
+        for (int i = (int)threadIdx.x + STAGE * WG_THREADS; i < n; i += WG_THREADS) lds_scene[i] = P.scene[i];
         __syncthreads();
     }
     const Lds S = make_lds<SCENE_LDS>(P, lds_scene, WG_TILES_X * WG_TILES_Y, threadIdx.x >> 6);
