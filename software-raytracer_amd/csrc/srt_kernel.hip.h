@@ -81,6 +81,7 @@ struct KernelParams {
     float mesh_r1;       // their sum + |centre|_1
     float mesh_bs_radius;  // radius of a sphere around mesh_center that contains every triangle
     int32_t mesh_defer;  // path pool: fewest rays that start a mesh phase (closest_hit)
+    int32_t mesh_wait;   // path pool: ... unless some ray has been waiting for this many steps
     int32_t tile_h;      // rows of a wave's pixel tile: 8, 4, 2 or 1 (pathtrace_kernel)
     // sample-chunked launches (DEFER instantiation): workgroup z traces samples [z*chunk, (z+1)*chunk) of
     // its tiles and stores the colours in sample order; fold_kernel then folds them into the running mean
@@ -291,7 +292,7 @@ __device__ __forceinline__ V3 ibox_normal(const BoxRay& br, V3 t1) {
 // round trips) follow from.  The host weighs them (srt_capi.hip, ProbeWeights).  Every other instantiation gets the empty
 // Tally: no code.  (Also counted in round 3 and dropped, their fitted weights came out at nothing: second halves of the sphere
 // test, trips of the scatter loop, fold iterations, boxes with a valid hit, steps with an environment lookup, traced and
-// untraced pixels.)
+// untraced pixels; rays per mesh phase.)
 enum {
     TALLY_STEPS = 0,       // pool steps (one closest_hit call of the whole wave each)
     TALLY_GROUPS,          // groups of four clustered spheres put through the exact test (a round of 64 items: K / 4)
@@ -1364,6 +1365,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         int rot = 0;  // wave-uniform rotation of the slot priority
         unsigned handed = 0;  // wave-uniform: samples handed out so far (n_hit x the mean own_next)
         const int fold_pace = (63 + n_hit) / n_hit;
+        int park_steps = 0;  // (mesh kernel) consecutive steps in which some ray waited for a mesh phase
 
         while (true) {
             SRT_TICK(7);
@@ -1551,7 +1553,10 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 o = v3(hp.x + hn.x * ofs, hp.y + hn.y * ofs, hp.z + hn.z * ofs);  // :177
             }
             // the scan runs in wave-uniform control flow: idle lanes help with other lanes' rays
-            const Hit h = closest_hit<MESH>(S, P, o, sray, busy, P.mesh_defer, parked, tally SRT_PROF_ARG);
+            // (a mesh phase waits for P.mesh_defer rays — but not for long: where mesh rays are rare a parked ray would hold its lane
+            // and, through the ring, its slot for many steps; after P.mesh_wait steps with someone parked the phase runs for whoever is there)
+            const Hit h = closest_hit<MESH>(S, P, o, sray, busy, MESH && park_steps >= P.mesh_wait ? 1 : P.mesh_defer, parked, tally SRT_PROF_ARG);
+            if constexpr (MESH) park_steps = __builtin_amdgcn_ballot_w64(busy && parked) != 0ull ? park_steps + 1 : 0;
             if (busy && !(MESH && parked)) {
                 ++rays;
                 bool end_path;

@@ -142,7 +142,9 @@ class MultiGpuRenderer {
     // RenderSamples; from then on, by default, bands of equal ESTIMATED cost (below).
     void Band(size_t i, int* begin, int* end) const;
     // Bands of equal ESTIMATED cost for the current scene, camera and bounce count (srt_estimate_row_costs on part 0:
-    // a device-side probe, ~0.1 ms), boundaries on multiples of 8 rows (16 was tried: too coarse for the 48..64-row floor bands of an 8-way 1080p split).  Equal bands leave the GPUs
+    // a device-side probe that runs the kernel's path pool over a quarter of the pixels for 32 samples and counts its loop
+    // trips — about 8 sample-frames of work, deterministic), boundaries on multiples of 2 rows (8 and 16 were tried: too coarse for
+    // the 48..64-row floor bands of an 8-way 1080p split).  Equal bands leave the GPUs
     // that own sky idle: on Scene1 the slowest of 8 equal bands takes 2.2x the average.  This is the DEFAULT
     // split: RenderSamples applies it whenever the accumulation (re)starts — after SetScene, Configure or Invalidate, when every
     // band starts from sample 1 anyway — so a caller never has to ask.  UseEqualBands(true) goes back to north_star's literal

@@ -5,7 +5,7 @@
         renders the bands of the 2 / 4 / 8-way splits that the given weights produce (one band after the other on one GPU) and
         stores, next to every band's kernel time, the probe's raw counts per block row (development library,
         srt_debug_probe_counts)
-  anywhere:         python3 tools/band_fit.py out1.json out2.json ...
+  anywhere:         python3 tools/band_fit.py [--fix=groups=660,waves=5830] out1.json out2.json ...
         least squares over all those runs: within every (run, N) group the bands should take the same time per unit of cost —
         log(cost_i / time_i) is to be the same for all bands i of a group — with the weights of the per-step part fixed
         (they only set the scale).  Prints the weights and each group's residuals; feed the weights to the next
@@ -42,6 +42,11 @@ def band_counts(doc, rb, re):
 
 
 def main(paths):
+    fixed = {}
+    if paths and paths[0].startswith("--fix="):  # --fix=groups=660,waves=5830: weights kept as given (e.g. fitted on another config)
+        fixed = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in paths[0][len("--fix="):].split(",")}
+        paths = paths[1:]
+    free = [k for k in FREE if k not in fixed]
     groups = []
     for f in paths:
         d = json.load(open(f))
@@ -54,7 +59,7 @@ def main(paths):
 
     def cost(C, sw, wv):
         c = sw * C[:, 0]
-        for k, v in zip(FREE, wv):
+        for k, v in list(zip(free, wv)) + list(fixed.items()):
             c = c + v * C[:, TALLY.index(k)]
         return c
 
@@ -64,11 +69,11 @@ def main(paths):
         for _, N, C, y, sw in groups:
             l = np.log(cost(C, sw, wv)) - np.log(y)
             r.append((l - l.mean()) * (1.0 if N > 2 else 0.5))
-        return np.concatenate(r + [0.05 * (p - np.log([PRIOR[k] for k in FREE]))])  # weak pull towards the first fit
+        return np.concatenate(r + [0.05 * (p - np.log([PRIOR[k] for k in free]))])  # weak pull towards the first fit
 
-    sol = least_squares(resid, np.log([PRIOR[k] for k in FREE]), loss="soft_l1", f_scale=0.05)
+    sol = least_squares(resid, np.log([PRIOR[k] for k in free]), loss="soft_l1", f_scale=0.05)
     wv = np.exp(sol.x)
-    print("weights: " + json.dumps({k: round(float(v), 1) for k, v in zip(FREE, wv)}))
+    print("weights: " + json.dumps({**{k: round(float(v), 1) for k, v in zip(free, wv)}, **fixed}))
     for f, N, C, y, sw in groups:
         l = np.log(cost(C, sw, wv)) - np.log(y)
         l -= l.mean()
