@@ -511,8 +511,9 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
     K.selected = p->selected_object;
     use = ctx->variant >= 0 ? ctx->variant : dev_switches().kernel;
     img = (use == 2) ? 1 : 0;  // variant 2: plain brute-force image
-    K.mesh_defer = use >= 100 && use < 200 ? use - 100 : 6;  // variants 100 + n: mesh phases wait for n rays
+    K.mesh_defer = use >= 100 && use < 200 ? use - 100 : 12;  // variants 100 + n: mesh phases wait for n rays
     K.mesh_wait = use >= 200 && use < 300 ? use - 200 : 3;   // variants 200 + w: ... for at most w steps
+    if (use >= 300 && use < 500) K.mesh_defer = (use - 300) / 10, K.mesh_wait = (use - 300) % 10;  // variants 300 + 10 n + w: both
 #ifdef SRT_DEV
     if (use >= 1000 && use < 2000) K.flags |= (uint32_t)(use - 1000) << 8;  // variants 1000 + f: kernel experiment flags f << 8
 #endif

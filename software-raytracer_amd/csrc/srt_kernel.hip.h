@@ -1553,7 +1553,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 o = v3(hp.x + hn.x * ofs, hp.y + hn.y * ofs, hp.z + hn.z * ofs);  // :177
             }
             // the scan runs in wave-uniform control flow: idle lanes help with other lanes' rays
-            // (a mesh phase waits for P.mesh_defer rays — but not for long: where mesh rays are rare a parked ray would hold its lane
+            // (a mesh phase waits for P.mesh_defer rays (12) — but not for long (P.mesh_wait = 3 steps): where mesh rays are rare a parked ray would hold its lane
             // and, through the ring, its slot for many steps; after P.mesh_wait steps with someone parked the phase runs for whoever is there)
             const Hit h = closest_hit<MESH>(S, P, o, sray, busy, MESH && park_steps >= P.mesh_wait ? 1 : P.mesh_defer, parked, tally SRT_PROF_ARG);
             if constexpr (MESH) park_steps = __builtin_amdgcn_ballot_w64(busy && parked) != 0ull ? park_steps + 1 : 0;
