@@ -125,12 +125,26 @@ typedef union srt_f32bits {
 }
 /* On the device the table lives in constant memory (and, for the kernels, as a copy in LDS: srt_powf_tab); host code of a HIP
  * translation unit reads the _host copy — a __constant__ variable has no usable host value. */
+/* The coefficients of srt_powf_tab's two polynomials and its range-reduction constants, as a table too: the kernels read them
+ * from their LDS copy (one broadcast read per term) instead of building each 64-bit literal with two moves in front of its FMA.
+ * [0..5] ln(1+s): 1/7, -1/6, 1/5, -1/4, 1/3, -1/2 | [6] LN2_HI (0x3fe62e42fee00000: e * LN2_HI is exact) | [7] LN2_LO
+ * (0x3dea39ef35793c76) | [8] 1/ln 2 | [9..17] e^r: 1/11!, 1/10!, ..., 1/3! | [18], [19] unused */
+#define SRT_POW_COEF_INIT { \
+    1.0 / 7.0, -1.0 / 6.0, 1.0 / 5.0, -1.0 / 4.0, 1.0 / 3.0, -0.5, \
+    6.93147180369123816490e-01, 1.90821492927058770002e-10, 1.44269504088896338700e+00, \
+    1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, \
+    0.0, 0.0 \
+}
 #if defined(__HIPCC__) || defined(__HIP__)
 __device__ __constant__ const double srt_pow_table[64] = SRT_POW_TABLE_INIT;
+__device__ __constant__ const double srt_pow_coef[20] = SRT_POW_COEF_INIT;
 static const double srt_pow_table_host[64] = SRT_POW_TABLE_INIT;
+static const double srt_pow_coef_host[20] = SRT_POW_COEF_INIT;
 #else
 static const double srt_pow_table[64] = SRT_POW_TABLE_INIT;
+static const double srt_pow_coef[20] = SRT_POW_COEF_INIT;
 #define srt_pow_table_host srt_pow_table
+#define srt_pow_coef_host srt_pow_coef
 #endif
 
 /* x^y for x >= 0 (x<0 -> NaN), finite y > 0.  Covers every call the path makes:
@@ -140,8 +154,8 @@ static const double srt_pow_table[64] = SRT_POW_TABLE_INIT;
  * result is the correctly rounded x^y except for about one input in a million (tests/test_defs.py: <= 1 ulp
  * from libm's powf on EVERY float of (0,1] for both exponents). */
 /* `table`: the 32 (invc, lnc) pairs above — srt_pow_table itself, or a copy of its bytes somewhere cheaper to read (the kernels
- * keep one in LDS next to the scene image; same values, same arithmetic, same bits). */
-SRT_HD float srt_powf_tab(float xf, float yf, const double* table) {
+ * keep one in LDS next to the scene image; same values, same arithmetic, same bits).  `coef`: srt_pow_coef or a copy of it. */
+SRT_HD float srt_powf_tab(float xf, float yf, const double* table, const double* coef) {
     srt_f32bits xb;
     xb.f = xf;
     if ((xb.u & 0x7fffffffU) > 0x7f800000U) return xf; /* NaN */
@@ -163,15 +177,14 @@ SRT_HD float srt_powf_tab(float xf, float yf, const double* table) {
     const double m = b.d;
     const double s = SRT_FMA(m, table[2 * i], -1.0);
     /* ln(1+s) = s + s^2 * (-1/2 + s/3 - s^2/4 + s^3/5 - s^4/6 + s^5/7) */
-    double p = 1.0 / 7.0;
-    p = SRT_FMA(p, s, -1.0 / 6.0);
-    p = SRT_FMA(p, s, 1.0 / 5.0);
-    p = SRT_FMA(p, s, -1.0 / 4.0);
-    p = SRT_FMA(p, s, 1.0 / 3.0);
-    p = SRT_FMA(p, s, -0.5);
+    double p = coef[0];
+    p = SRT_FMA(p, s, coef[1]);
+    p = SRT_FMA(p, s, coef[2]);
+    p = SRT_FMA(p, s, coef[3]);
+    p = SRT_FMA(p, s, coef[4]);
+    p = SRT_FMA(p, s, coef[5]);
     const double lnm = SRT_FMA(s * s, p, s);
-    const double LN2_HI = 6.93147180369123816490e-01; /* 0x3fe62e42fee00000: e * LN2_HI is exact */
-    const double LN2_LO = 1.90821492927058770002e-10; /* 0x3dea39ef35793c76 */
+    const double LN2_HI = coef[6], LN2_LO = coef[7];
     const double ed = (double)e;
     const double lnx = SRT_FMA(ed, LN2_HI, table[2 * i + 1] + SRT_FMA(ed, LN2_LO, lnm));
     const double t = (double)yf * lnx;
@@ -183,19 +196,19 @@ SRT_HD float srt_powf_tab(float xf, float yf, const double* table) {
         return inf.f;
     }
     if (t < -104.0) return 0.0f;
-    const double kd = t * 1.44269504088896338700e+00;
+    const double kd = t * coef[8];
     const int k = (int)(kd < 0.0 ? kd - 0.5 : kd + 0.5);
     const double kk = (double)k;
     const double r = SRT_FMA(-kk, LN2_LO, SRT_FMA(-kk, LN2_HI, t));
-    double q = 1.0 / 39916800.0; /* 1/11! */
-    q = SRT_FMA(q, r, 1.0 / 3628800.0);
-    q = SRT_FMA(q, r, 1.0 / 362880.0);
-    q = SRT_FMA(q, r, 1.0 / 40320.0);
-    q = SRT_FMA(q, r, 1.0 / 5040.0);
-    q = SRT_FMA(q, r, 1.0 / 720.0);
-    q = SRT_FMA(q, r, 1.0 / 120.0);
-    q = SRT_FMA(q, r, 1.0 / 24.0);
-    q = SRT_FMA(q, r, 1.0 / 6.0);
+    double q = coef[9]; /* 1/11! */
+    q = SRT_FMA(q, r, coef[10]);
+    q = SRT_FMA(q, r, coef[11]);
+    q = SRT_FMA(q, r, coef[12]);
+    q = SRT_FMA(q, r, coef[13]);
+    q = SRT_FMA(q, r, coef[14]);
+    q = SRT_FMA(q, r, coef[15]);
+    q = SRT_FMA(q, r, coef[16]);
+    q = SRT_FMA(q, r, coef[17]);
     q = SRT_FMA(q, r, 0.5);
     q = SRT_FMA(q, r, 1.0);
     q = SRT_FMA(q, r, 1.0);
@@ -210,6 +223,6 @@ SRT_HD float srt_powf_tab(float xf, float yf, const double* table) {
     return (float)q;
 }
 
-SRT_HD float srt_powf(float xf, float yf) { return srt_powf_tab(xf, yf, srt_pow_table); }
+SRT_HD float srt_powf(float xf, float yf) { return srt_powf_tab(xf, yf, srt_pow_table, srt_pow_coef); }
 
 #endif /* SRT_DEFS_H */

@@ -828,9 +828,9 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
         else hipLaunchKernelGGL(k_hbm, grid, block, lds_bytes, ctx->stream, K);
     };
     if (K.n_tris > 0)  // EXTENSION: scenes with triangle meshes use the BVH-enabled instantiation
-        launch(srt::pathtrace_kernel<4, true, true, false, false>, srt::pathtrace_kernel<3, true, true, true, false>,
+        launch(srt::pathtrace_kernel<4, true, true, false, false>, srt::pathtrace_kernel<4, true, true, true, false>,
                srt::pathtrace_kernel<4, true, true, false, true>, srt::pathtrace_kernel<4, true, false, false, false>,
-               srt::pathtrace_kernel<3, true, false, true, false>, srt::pathtrace_kernel<4, true, false, false, true>);
+               srt::pathtrace_kernel<4, true, false, true, false>, srt::pathtrace_kernel<4, true, false, false, true>);
 #ifdef SRT_DEV  // occupancy variants for A/B timing; never in the shipped library
     else if (use == 1 && in_lds && !multi && !defer)
         hipLaunchKernelGGL((srt::pathtrace_kernel<4, false>), grid, block, lds_bytes, ctx->stream, K);
@@ -838,11 +838,12 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
         hipLaunchKernelGGL((srt::pathtrace_kernel<3, false>), grid, block, lds_bytes, ctx->stream, K);
 #endif
     else
-        // (five waves per SIMD, 96 VGPRs: the full-tile and the sample-chunk instantiations fit without a spill; the multi-sample
-        // hand-out of small tiles / progressive blocks would spill 16 registers and stays at four)
-        launch(srt::pathtrace_kernel<5, false, true, false, false>, srt::pathtrace_kernel<4, false, true, true, false>,
+        // (five waves per SIMD, 96 VGPRs.  Since srt_powf's coefficients come from the LDS constants block — the 64-bit literals had
+        // been living in hoisted register pairs — the kernels need 85..95 registers, the multi-sample hand-out of small tiles /
+        // progressive blocks included (it stayed at four waves before: 111), and the mesh kernels 119..125: four waves, no spill)
+        launch(srt::pathtrace_kernel<5, false, true, false, false>, srt::pathtrace_kernel<5, false, true, true, false>,
                srt::pathtrace_kernel<5, false, true, false, true>, srt::pathtrace_kernel<5, false, false, false, false>,
-               srt::pathtrace_kernel<4, false, false, true, false>, srt::pathtrace_kernel<5, false, false, false, true>);
+               srt::pathtrace_kernel<5, false, false, true, false>, srt::pathtrace_kernel<5, false, false, false, true>);
     if (defer) {
         SRT_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(srt::fold_kernel, dim3((unsigned)wg8), dim3(256), 0, ctx->stream, K, (int)wg_x);

@@ -225,7 +225,7 @@ __device__ __forceinline__ V3 normalized(V3 a) {
 __device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 
 
-constexpr int CONST_ROWS = 36, CONST_ENV_ROW = 32;  // srt_scene_image.h: SRT_CONST_ROWS / SRT_CONST_ENV_ROW
+constexpr int CONST_ROWS = 46, CONST_ENV_ROW = 32, CONST_COEF_ROW = 36;  // srt_scene_image.h: SRT_CONST_ROWS / SRT_CONST_ENV_ROW / SRT_CONST_COEF_ROW
 struct Lds {
     const float4* c;  // the image's constants block: srt_powf's table (32 rows), the environment (4 rows)
     const float4* v;  // the primitives behind it (all offsets below count from here)
@@ -952,7 +952,7 @@ __device__ __forceinline__ RGB environment(const Lds& S, V3 d) {
     // one srt_powf call site for both branches (:81 powf(upd, 0.1f) / :87 powf(|upd|, .05f)):
     // the arguments are selected per lane, so up- and down-going lanes do not serialize.
     const bool up = upd > 0;
-    const float pw = srt_powf_tab(up ? upd : fabsf(upd), up ? 0.1f : .05f, reinterpret_cast<const double*>(S.c));
+    const float pw = srt_powf_tab(up ? upd : fabsf(upd), up ? 0.1f : .05f, reinterpret_cast<const double*>(S.c), reinterpret_cast<const double*>(S.c + CONST_COEF_ROW));
     RGB t;
     if (up) {
         t = color_lerp(Horizon, Sky, pw);  // :81

@@ -9,6 +9,8 @@
 //     rows 32..35  the environment (Raytracer.cpp:55-59), colours clamped like Color's constructor (Common.hpp:253-262):
 //                  (sky.rgb, sun.r) (horizon.rgb, sun.g) (ground.rgb, sun.b) (sunDirection.xyz, 0) — patched in place by
 //                  srt_set_environment, out of the kernel's argument registers
+//     rows 36..45  srt_pow_coef: the coefficients of srt_powf's two polynomials and its range-reduction constants (20 doubles) —
+//                  one broadcast LDS read per term instead of two moves that build the 64-bit literal in front of every FMA
 //   [0, nu4)                 "uniform" spheres (cx,cy,cz,r*r), list order, padded to a
 //                            multiple of 4 with never-hit dummies (0,0,0,-1).  Every lane
 //                            tests all of them (wave-uniform broadcast reads).
@@ -60,7 +62,7 @@
 
 namespace srt {
 
-constexpr int SRT_CONST_ROWS = 36, SRT_CONST_ENV_ROW = 32;
+constexpr int SRT_CONST_ROWS = 46, SRT_CONST_ENV_ROW = 32, SRT_CONST_COEF_ROW = 36;  // (rows 36-45: srt_pow_coef, 20 doubles)
 
 struct SceneLayout {
     int nu4 = 0;      // uniform sphere slots (multiple of 4)
@@ -212,6 +214,7 @@ inline SceneLayout build_scene_image(const srt_object* objects, size_t count, bo
 
     std::vector<float4> full((size_t)L.total_vec4, make_float4(0, 0, 0, 0));
     memcpy(full.data(), srt_pow_table_host, 32 * sizeof(float4));  // 64 doubles = 32 rows; the environment rows are patched by the caller
+    memcpy(full.data() + SRT_CONST_COEF_ROW, srt_pow_coef_host, 10 * sizeof(float4));
     img.assign((size_t)std::max(L.total_vec4 - SRT_CONST_ROWS, 1), make_float4(0, 0, 0, 0));
     const float4 dummy = make_float4(0, 0, 0, -1.0f);  // d2 > r*r always: never a candidate
     for (int p = 0; p < L.nsT; ++p) img[p] = dummy;
