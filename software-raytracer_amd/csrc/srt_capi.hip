@@ -652,6 +652,13 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
         if (K.n_tris == 0) {
             const long long c_fill = (10LL * 5 * ctx->cu_count + wg8 - 1) / wg8;
             if (c < c_fill) c = c_fill;
+        } else {
+            // Mesh launches: four rounds of their four workgroups per CU.  Every chunk repeats the primary rays' mesh phases, so
+            // chunks are dearer than for analytic scenes and the cost order does well on uneven bands (config 5's rows 1080-1350,
+            // 4 rounds in one piece: 48.6 ms, 50.5 with two chunks) — but a narrow band of evenly dear blocks left in one piece is
+            // 1.9 rounds: config 5's floor band 1812-1938 76.9 ms, 74.6 with two chunks, 72.9 with eight.
+            const long long c_fill = (4LL * 4 * ctx->cu_count + wg8 / 2) / wg8;  // (to the nearest: 4080 blocks are four rounds)
+            if (c < c_fill) c = c_fill;
         }
         if (c > p->sample_count / min_chunk) c = p->sample_count / min_chunk;
         // A mesh launch that the rule leaves in ONE piece keeps full 8 x 8 tiles: the small tiles chosen above for launches of few
