@@ -32,6 +32,10 @@ WORK = {  # name: scene, mesh, width, height, spp, bounces, memory rows (None = 
     "c5n112": ("Scene1", 224, 3840, 2160, 1024, 16, (1592, 1704)),
     "c5n128": ("Scene1", 224, 3840, 2160, 1024, 16, (1360, 1488)),
     "1spp": ("Scene1", 0, 1920, 1080, 1, 8, None),
+    "c5sky": ("Scene1", 224, 3840, 2160, 1024, 16, (0, 1066)),   # bands of the cost-balanced 8-rank split of config 5, final kernels
+    "c5hor": ("Scene1", 224, 3840, 2160, 1024, 16, (1066, 1388)),
+    "c5floor": ("Scene1", 224, 3840, 2160, 1024, 16, (1812, 1938)),
+    "c3sky": ("Scene1", 0, 1920, 1080, 512, 8, (0, 474)),
     "1spp_ind": ("Scene_indirect", 0, 1920, 1080, 1, 8, None),
     "1spp_c4": ("Scene1", 224, 1920, 1080, 1, 8, None),
 }
