@@ -127,7 +127,7 @@ struct srt_context {
     bool recording = false;               // a cost copy is in flight (ev_cost)
     bool order_stale = true;              // scene / camera changed since the costs were recorded
     double cost_sum = 0.0;                // of the last recorded block costs (0: none), their maximum and their grid:
-    uint32_t cost_max = 0;                //   (99.5th percentile) how uneven the blocks are decides the number of sample chunks
+    uint32_t cost_max = 0;                //   the dearest block: how uneven the blocks are decides the number of sample chunks
     unsigned cost_gx = 0, cost_gy = 0;
     int band_y0 = -1, band_rows = -1;     // the row band the order, the recording and the cost figures above belong to
     bool estimate_stale = true;           // the scene changed since the order was last estimated on the device
@@ -674,7 +674,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     if (chunks >= 2) {
         const size_t tiles = (size_t)wg8 * srt::WG_TILES_X * srt::WG_TILES_Y;
         const size_t need = tiles * (size_t)p->sample_count * 64 * sizeof(float4);
-        bool ok = need <= ((size_t)24 << 30);
+        bool ok = need <= ((size_t)96 << 30);  // (a third of the 288 GB; 24 GB until round 3 — the sky half of config 5 at 4K x 1024 spp needs 67)
         if (ok && need > ctx->samples_capacity) {  // growing: take at most a quarter of what is free
             size_t free_b = 0, total_b = 0;
             ok = hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= (free_b + ctx->samples_capacity) / 4;
@@ -775,13 +775,10 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
                 fprintf(stderr, "costs arrived: %zu blocks, %zu suspicious, grid %u x %u\n", n, bad, ctx->rec_gx, ctx->rec_gy);
             }
 #endif
-            {  // what the sample-chunk rule looks at: the 99.5th percentile stands for the dearest block (one block's count
-               // can be inflated by whatever else the launch's first workgroups wait for)
-                std::vector<uint32_t> tmp(ctx->h_wg_cost, ctx->h_wg_cost + n);
-                const size_t k = n - 1 - n / 200;
-                std::nth_element(tmp.begin(), tmp.begin() + k, tmp.end());
-                ctx->cost_sum = sum, ctx->cost_max = tmp[k], ctx->cost_gx = ctx->rec_gx, ctx->cost_gy = ctx->rec_gy;
-            }
+            // What the sample-chunk rule looks at: the dearest block — the maximum itself (a 99.5th percentile until round 3, from the
+            // days of the block-cost timer's stray records, §4.3; a record that is too high costs a few chunks too many, a dear block
+            // that is overlooked costs the tail).
+            ctx->cost_sum = sum, ctx->cost_max = hi, ctx->cost_gx = ctx->rec_gx, ctx->cost_gy = ctx->rec_gy;
             const double scale = hi > lo ? (double)(NB - 1) / (double)(hi - lo) : 0.0;
             auto bucket = [&](uint32_t c) { return (NB - 1) - (int)((double)(c - lo) * scale); };
             std::vector<size_t> start((size_t)NB + 1, 0);
