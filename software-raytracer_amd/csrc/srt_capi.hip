@@ -524,6 +524,7 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
     K.K = SL.K;
     K.nsT = SL.nsT;
     K.nb = SL.nb;
+    if (SL.boxes_finite) K.flags |= srt::KF_BOXES_FINITE;
     K.off_bounds = SL.off_bounds;
     K.off_box = SL.off_box;
     K.off_mat = SL.off_mat;
@@ -1015,7 +1016,7 @@ static int run_pool_probe(srt_context* ctx, int max_bounces, uint32_t seed, std:
     size_t lds_bytes = 0;
     int use = 0, img = 0;
     fill_kernel_params(ctx, &p, K, lds_bytes, use, img);
-    K.flags = SRT_RENDER_RESET;
+    K.flags = (K.flags & srt::KF_BOXES_FINITE) | SRT_RENDER_RESET;
     K.tile_h = srt::TILE_H;
     K.accumulator = nullptr, K.framebuffer = nullptr, K.ray_counter = nullptr;  // the probe touches none of them
     bx = (W + srt::WG_W - 1) / srt::WG_W, by = (H + srt::WG_H - 1) / srt::WG_H;

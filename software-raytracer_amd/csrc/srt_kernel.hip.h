@@ -45,6 +45,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "srt_defs.h"
 
 namespace srt {
@@ -100,6 +102,7 @@ struct KernelParams {
 // internal KernelParams.flags bit (srt_render sets it): progressive-block launch whose lanes stand for steps x steps
 // blocks instead of pixels — a lane traces its block's ray and writes all of the block's pixels
 constexpr uint32_t KF_BLOCK_GRID = 0x10u;
+constexpr uint32_t KF_BOXES_FINITE = 0x20u;  // (srt_set_scene found every box centre and half size finite: closest_hit's NaN-free slab test)
 constexpr uint32_t SRT_MESH_ORDER_W = 6u;  // block_cost_kernel: ordering cost of a ray that ends on a mesh, in analytic rays (as the balance cost)
 constexpr int TILE_W = 8, TILE_H = 8;       // per wavefront
 constexpr int WG_TILES_X = 2, WG_TILES_Y = 2;  // waves per workgroup
@@ -264,16 +267,18 @@ __device__ __forceinline__ BoxRay box_ray_setup(V3 rd) {
     return b;
 }
 // Box::iBox (Object.hpp:173-200) distance part; t1 out for the normal.
-// (Round 3 tried v_max3_f32 / v_min3_f32 for tN / tF — one instruction instead of four compare-and-select pairs — behind a
-// wave-uniform test that no ray that counts carries a NaN: Scene_indirect -0.3 %, Scene3 -1.1 %, but the second copy of the box
-// loop cost the analytic kernel four spilled registers and Scene1 +1.6 %.  Dropped.)
+// NO_NAN: the caller has seen that origin and direction of every lane that counts are finite and that the scene's boxes are; then
+// no slab distance is a NaN (slopes are +-1e8 at most in size, or +0 for a zero component) and `a > b ? a : b` differs from the
+// hardware's max / min only in which zero comes out of (+0, -0) — and tN, tF go nowhere but into comparisons and, from 0.01 up,
+// into the result: one v_max3_f32 / v_min3_f32 instead of four compare-and-select pairs.
+template <bool NO_NAN>
 __device__ __forceinline__ float ibox_dist(const BoxRay& br, V3 ro, V3 size, V3& t1) {
     V3 n = v3(br.m.x * ro.x, br.m.y * ro.y, br.m.z * ro.z);
     V3 k = v3(br.am.x * size.x, br.am.y * size.y, br.am.z * size.z);
     t1 = v3(n.x * -1 - k.x, n.y * -1 - k.y, n.z * -1 - k.z);
     V3 t2 = v3(n.x * -1 + k.x, n.y * -1 + k.y, n.z * -1 + k.z);
-    float tN = tmax(tmax(t1.x, t1.y), t1.z);
-    float tF = tmin(tmin(t2.x, t2.y), t2.z);
+    float tN = NO_NAN ? __builtin_fmaxf(__builtin_fmaxf(t1.x, t1.y), t1.z) : tmax(tmax(t1.x, t1.y), t1.z);
+    float tF = NO_NAN ? __builtin_fminf(__builtin_fminf(t2.x, t2.y), t2.z) : tmin(tmin(t2.x, t2.y), t2.z);
     const float FMAX = 3.402823466e+38f;
     if (tN > tF || tF <= 0.0f) return FMAX;
     if (tN >= (float)0.01 && tN <= 10000.0f) return tN;
@@ -521,24 +526,32 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
     const int nsT = S.nsT, nb = S.nb;
     if (nb > 0) {
         br = box_ray_setup(d);
-        for (int j = 0; j < nb; ++j) {
-            const float4 c = S.box_c(j), hs = S.box_h(j);
-            V3 t1;
-            float dist = ibox_dist(br, v3(o.x - c.x, o.y - c.y, o.z - c.z), v3(hs.x, hs.y, hs.z), t1);
-            bool valid = active && dist != 3.402823466e+38f;  // Object.hpp:231
-            if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
-                const bool tie = valid & (dist == best) & (bp >= 0);
-                bool win = valid & (dist < best);
-                if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // rare: list indices only on an exact tie
-                    const int ob = S.order(tie ? bp : nsT + j);
-                    win = win | (tie & (S.order(nsT + j) < ob));
+        // (a NaN or infinity anywhere in a ray that counts — the sum is then not finite; so is, harmlessly, a sum that overflows —
+        // sends the wave through the comparisons as the reference writes them)
+        const float fin = ((o.x + o.y) + o.z) + ((d.x + d.y) + d.z);
+        const bool no_nan = (P.flags & KF_BOXES_FINITE) != 0 && __builtin_amdgcn_ballot_w64(active && !(fabsf(fin) < __builtin_inff())) == 0ull;
+        auto boxes = [&](auto tag) {
+            for (int j = 0; j < nb; ++j) {
+                const float4 c = S.box_c(j), hs = S.box_h(j);
+                V3 t1;
+                float dist = ibox_dist<decltype(tag)::value>(br, v3(o.x - c.x, o.y - c.y, o.z - c.z), v3(hs.x, hs.y, hs.z), t1);
+                bool valid = active && dist != 3.402823466e+38f;  // Object.hpp:231
+                if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
+                    const bool tie = valid & (dist == best) & (bp >= 0);
+                    bool win = valid & (dist < best);
+                    if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // rare: list indices only on an exact tie
+                        const int ob = S.order(tie ? bp : nsT + j);
+                        win = win | (tie & (S.order(nsT + j) < ob));
+                    }
+                    best = win ? dist : best;
+                    bp = win ? nsT + j : bp;
+                    // component-wise: a whole-struct select is lowered to a pointer select + copies through scratch
+                    bt1 = v3(win ? t1.x : bt1.x, win ? t1.y : bt1.y, win ? t1.z : bt1.z);
                 }
-                best = win ? dist : best;
-                bp = win ? nsT + j : bp;
-                // component-wise: a whole-struct select is lowered to a pointer select + copies through scratch
-                bt1 = v3(win ? t1.x : bt1.x, win ? t1.y : bt1.y, win ? t1.z : bt1.z);
             }
-        }
+        };
+        if (no_nan) boxes(std::true_type{});
+        else boxes(std::false_type{});
     }
     // ---- 4. EXTENSION: triangle meshes — traversal of the host-built 8-wide BVH (HBM/L2).
     // The triangle arithmetic is this project's definition (srt_pathtrace.h); the box filter is

@@ -75,6 +75,7 @@ struct SceneLayout {
     int off_bounds = 0, off_box = 0, off_mat = 0;
     int total_vec4 = 0;
     int n_spheres = 0;  // real spheres (for statistics)
+    bool boxes_finite = true;  // every box centre and half size is a finite number (the kernel's NaN-free slab test relies on it)
 };
 
 // the four environment rows of the constants block (colours through Color's clamping constructor, Common.hpp:253-262)
@@ -286,6 +287,7 @@ inline SceneLayout build_scene_image(const srt_object* objects, size_t count, bo
         const srt_object& o = objects[boxes[j]];
         img[L.off_box + 2 * j] = make_float4(o.position[0], o.position[1], o.position[2], 0.0f);
         img[L.off_box + 2 * j + 1] = make_float4(o.half_size[0], o.half_size[1], o.half_size[2], 0.0f);
+        for (int a = 0; a < 3; ++a) L.boxes_finite = L.boxes_finite && std::isfinite(o.position[a]) && std::isfinite(o.half_size[a]);
         put_material(L.nsT + (int)j, boxes[j]);
     }
     for (size_t m = 0; m < meshobjs.size(); ++m) put_material(L.nsT + L.nb + (int)m, meshobjs[m]);

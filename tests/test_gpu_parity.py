@@ -75,6 +75,37 @@ def test_random_large_scenes(srt, oracle, nsph, nbox):
     pt.close()
 
 
+@pytest.mark.parametrize("case", ["inf half size", "nan centre", "inf camera", "finite"])
+def test_boxes_with_non_finite_numbers(srt, oracle, case):
+    """The box slab test has a NaN-free form (v_max3 / v_min3) that the kernel may only take when the scene's boxes and every ray
+    that counts are finite; anything else goes through the comparisons as the reference writes them.  Scenes and cameras on
+    both sides of that decision, bit-exact vs the oracle."""
+    inf, nan = float("inf"), float("nan")
+    objs = [dict(type=oracle.OBJ_SPHERE, position=(0, -1001, 5), radius=1000, base=(.8, .8, .8)),
+            dict(type=oracle.OBJ_BOX, position=(0.5, 0.5, 6), half_size=(0.7, 0.5, 0.6), base=(.3, .6, .9), smoothness=0.8, specular_amount=0.5),
+            dict(type=oracle.OBJ_BOX, position=(-1.5, 0.2, 5), half_size=(0.4, 0.4, 0.4), base=(.9, .4, .3)),
+            dict(type=oracle.OBJ_SPHERE, position=(1.5, 0.3, 4), radius=0.5, base=(.5, .9, .5), emissive=(1, 1, 1))]
+    if case == "inf half size":
+        objs.append(dict(type=oracle.OBJ_BOX, position=(3, 1, 8), half_size=(inf, 0.5, 0.5), base=(.5, .5, .5)))
+    if case == "nan centre":
+        objs.append(dict(type=oracle.OBJ_BOX, position=(nan, 1, 8), half_size=(0.5, 0.5, 0.5), base=(.5, .5, .5)))
+    oarr, n = oracle.make_objects(objs)
+    cam, ocam = srt.default_camera(), oracle.default_camera()
+    if case == "inf camera":
+        cam.position = (C.c_float * 3)(0.0, inf, 0.0)
+        ocam.position = (C.c_float * 3)(0.0, inf, 0.0)
+    w, h = 96, 54
+    pt = srt.PathTracer(w, h)
+    pt.set_scene(C.cast(oarr, C.POINTER(srt.Object)), n)
+    pt.set_camera(cam)
+    pt.render(spp=4, bounces=6, seed=2, count_rays=True)
+    ofb, oacc, orays = oracle.render(oarr, n, oracle.default_environment(), ocam, w, h, spp=4, bounces=6, seed=2)
+    assert pt.stats().rays == orays
+    assert np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32))
+    assert np.array_equal(pt.framebuffer(), ofb)
+    pt.close()
+
+
 def test_object_count_limit(srt, oracle):
     """The hit key holds the list index in 15 bits: 32768 objects are refused with a message, 4000 (an
     image beyond LDS, served from HBM — see test_scene_larger_than_lds) are accepted."""
