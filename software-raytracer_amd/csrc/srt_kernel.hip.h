@@ -88,6 +88,7 @@ struct KernelParams {
     // sample-chunked launches (DEFER instantiation): workgroup z traces samples [z*chunk, (z+1)*chunk) of
     // its tiles and stores the colours in sample order; fold_kernel then folds them into the running mean
     int32_t chunk;           // samples per workgroup, 0 = everything in one workgroup (no sample buffer)
+    int32_t chunk_full;      // grid layers z < chunk_full trace `chunk` samples each, the layers behind them half as many (the launch's tail)
     float4* sample_rows;     // [tile][sample][64 slots] sample colours
     unsigned long long* tile_masks;  // [tile] which pixels of the tile are traced (slot k = k-th set bit)
     // cost-ordered dispatch: workgroup i of the launch works on tile block wg_order[i] (NULL: i); every
@@ -1239,8 +1240,15 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
 
     const bool reset = (P.flags & 1u) != 0;
     // samples of this workgroup: all of them, or chunk blockIdx.z of the launch
-    const uint32_t s_base = DEFER ? blockIdx.z * (uint32_t)P.chunk : 0u;
-    const uint32_t count = DEFER ? (P.sample_count - s_base < (uint32_t)P.chunk ? P.sample_count - s_base : (uint32_t)P.chunk) : P.sample_count;
+    // (the last layers of the grid — the last workgroups to start — trace half chunks: the launch's tail is as long as its
+    // last workgroups run)
+    uint32_t s_base = 0u, count = P.sample_count;
+    if constexpr (DEFER) {
+        const uint32_t z = blockIdx.z, zf = (uint32_t)P.chunk_full, S = (uint32_t)P.chunk, half = S >> 1;
+        s_base = z < zf ? z * S : zf * S + (z - zf) * half;
+        const uint32_t want = z < zf ? S : half;
+        count = P.sample_count - s_base < want ? P.sample_count - s_base : want;
+    }
     const int B = P.max_bounces;
     unsigned rays = 0;
 
