@@ -701,15 +701,19 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     K.tile_h = tile_h;
     K.chunk = defer ? chunk : 0;
     K.chunk_full = chunks;
-    // Taper (analytic launches of four chunks and more): the last two chunks become four of half the size.  The grid's last layers
-    // are the last workgroups to start, and a launch ends when its last workgroups do — in a band of evenly dear blocks that tail is
-    // one workgroup's run time, an eighth of a 5 ms band.  Config 3's bands of 60..200 rows -2..-8 %, its 820-row band -2 %
-    // (tools/chunk_sweep.py with SRT_KFLAGS=1024 switching it off, profiles/r03/ab_notes.txt); three or four tapered chunks: the same.
-    if (defer && K.n_tris == 0 && chunks >= 4 && chunk >= 24 && !(dev_switches().kernel_flags & 0x400)) {
-        const int half = chunk >> 1, full = chunks - 2;                                // layers that keep the full size
-        const long long rest = (long long)p->sample_count - (long long)full * chunk;  // samples behind them (the last chunk may be short)
-        K.chunk_full = full;
-        chunks = full + (int)((rest + half - 1) / half);
+    // Taper: the last two chunks of a launch (the last one, when there are only two or three) run as twice as many of half the size.
+    // The grid's last layers are the last workgroups to start, and a launch ends when its last workgroups do — in a band of evenly
+    // dear blocks that tail is one workgroup's run time, an eighth of a 5 ms band.  Config 3's bands of 60..200 rows -2..-8 %, its
+    // 820-row band -2 %, the whole frame -1 %; config 5's chunked bands (mesh) -6..-9 % (tools/chunk_sweep.py with SRT_KFLAGS=1024
+    // switching it off, profiles/r03/ab_notes.txt); three or four tapered chunks: the same as two.
+    {
+        const int taper = chunks >= 4 ? 2 : 1;
+        if (defer && chunk >= 24 && !(dev_switches().kernel_flags & 0x400)) {
+            const int half = chunk >> 1, full = chunks - taper;                            // layers that keep the full size
+            const long long rest = (long long)p->sample_count - (long long)full * chunk;  // samples behind them (the last chunk may be short)
+            K.chunk_full = full;
+            chunks = full + (int)((rest + half - 1) / half);
+        }
     }
     K.sample_rows = ctx->d_samples;
     K.tile_masks = ctx->d_tile_masks;
