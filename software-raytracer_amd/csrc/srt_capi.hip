@@ -126,6 +126,7 @@ struct srt_context {
     unsigned rec_gx = 0, rec_gy = 0;      // grid of the recording in flight
     bool recording = false;               // a cost copy is in flight (ev_cost)
     bool order_stale = true;              // scene / camera changed since the costs were recorded
+    double cost_fill = 0.0;               // recorded wave time / (the recorded launch's time x resident waves), 0: unknown
     double cost_sum = 0.0;                // of the last recorded block costs (0: none), their maximum and their grid:
     uint32_t cost_max = 0;                //   the dearest block: how uneven the blocks are decides the number of sample chunks
     unsigned cost_gx = 0, cost_gy = 0;
@@ -373,7 +374,7 @@ static int set_scene_impl(srt_context* ctx, const srt_object* objects, size_t co
     ctx->scene_set = true;
     ctx->order_stale = true;
     ctx->estimate_stale = true;
-    ctx->cost_sum = 0.0;  // the recorded block costs describe another scene
+    ctx->cost_sum = 0.0, ctx->cost_fill = 0.0;  // the recorded block costs describe another scene
     // ... and so does a cost copy that may still be in flight, and the dispatch order made from the old scene's costs: both are
     // dropped (the stream was synchronised above, so nothing still writes h_wg_cost), the next launch estimates afresh
     ctx->recording = false;
@@ -580,7 +581,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     if (K.y0 != ctx->band_y0 || K.rows != ctx->band_rows) {
         ctx->band_y0 = K.y0, ctx->band_rows = K.rows;
         ctx->order_stale = ctx->estimate_stale = true;
-        ctx->cost_sum = 0.0;
+        ctx->cost_sum = 0.0, ctx->cost_fill = 0.0;
         ctx->recording = false;
         ctx->order_gx = ctx->order_gy = 0;
     }
@@ -641,7 +642,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             const double ratio = (double)ctx->cost_max * slots / ctx->cost_sum;
             c = ratio < 0.85 ? (K.n_tris > 0 ? 1 : 2) : (long long)ceil(ratio * 100.0 / (double)dev_switches().chunk_beta);
 #ifdef SRT_DEV
-            if (getenv("SRT_DEBUG_CHUNKS")) fprintf(stderr, "chunks: dearest %u sum %.0f blocks %lld slots %.0f ratio %.3f -> c %lld\n", ctx->cost_max, ctx->cost_sum, wg8, slots, ratio, c);
+            if (getenv("SRT_DEBUG_CHUNKS")) fprintf(stderr, "chunks: dearest %u sum %.0f blocks %lld slots %.0f ratio %.3f fill %.3f -> c %lld\n", ctx->cost_max, ctx->cost_sum, wg8, slots, ratio, ctx->cost_fill, c);
 #endif
         }
         // Analytic scenes, round 3 (five resident workgroups per CU, ring of two): at least ten rounds of workgroups, whatever the
@@ -660,6 +661,11 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             // 1.9 rounds: config 5's floor band 1812-1938 76.9 ms, 74.6 with two chunks, 72.9 with eight.
             const long long c_fill = (4LL * 4 * ctx->cu_count + wg8 / 2) / wg8;  // (to the nearest: 4080 blocks are four rounds)
             if (c < c_fill) c = c_fill;
+            // ... and a launch that left a quarter of the chip's wave slots empty is cut into four: the upper 1066 rows of config 5
+            // (sky, far spheres, mirror balls: half of its blocks cost nothing, the dear ones make 4.5 rounds) filled 0.73 of the
+            // slots in one piece, 76.8 ms; 66.5 with three chunks, 64.4 with six.  Its neighbours fill 0.94..0.96 and lose 1..5 %
+            // to any chunking — no figure of the cost record itself tells them apart, the launch's own time does.
+            if (ctx->cost_fill > 0.0 && ctx->cost_fill < 0.85 && c < 4 && ctx->cost_gx == (unsigned)wg_x && ctx->cost_gy == (unsigned)wg_y8) c = 4;
         }
         if (c > p->sample_count / min_chunk) c = p->sample_count / min_chunk;
         // A mesh launch that the rule leaves in ONE piece keeps full 8 x 8 tiles: the small tiles chosen above for launches of few
@@ -795,6 +801,15 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             // days of the block-cost timer's stray records, §4.3; a record that is too high costs a few chunks too many, a dear block
             // that is overlooked costs the tail).
             ctx->cost_sum = sum, ctx->cost_max = hi, ctx->cost_gx = ctx->rec_gx, ctx->cost_gy = ctx->rec_gy;
+            {   // how full the chip was during the recorded launch: the waves' run time (10 ns ticks) against the launch's own time
+                // (its events completed before the cost copy did) x the waves a chip holds of this kernel
+                float ms = 0.0f;
+                ctx->cost_fill = 0.0;
+                if (hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end) == hipSuccess && ms > 0.0f)
+                    ctx->cost_fill = sum * 1e-5 / ((double)ms * ctx->cu_count * (ctx->mesh_image.n_tris > 0 ? 16.0 : 20.0));
+                else
+                    (void)hipGetLastError();
+            }
             const double scale = hi > lo ? (double)(NB - 1) / (double)(hi - lo) : 0.0;
             auto bucket = [&](uint32_t c) { return (NB - 1) - (int)((double)(c - lo) * scale); };
             std::vector<size_t> start((size_t)NB + 1, 0);
