@@ -12,6 +12,7 @@ from conftest import ROOT
 
 def test_band_fit_runs_on_the_committed_iterations():
     files = sorted(os.path.join(ROOT, "profiles", "r03", "band_fit", f) for f in os.listdir(os.path.join(ROOT, "profiles", "r03", "band_fit")))
+    files = [f for f in files if int(f.split('iter')[1][0]) <= 4]  # the four joint iterations (5 and 6: config 5 alone, mesh weights only)
     assert len(files) == 8
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "band_fit.py")] + files, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
