@@ -665,7 +665,9 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             // (sky, far spheres, mirror balls: half of its blocks cost nothing, the dear ones make 4.5 rounds) filled 0.73 of the
             // slots in one piece, 76.8 ms; 66.5 with three chunks, 64.4 with six.  Its neighbours fill 0.94..0.96 and lose 1..5 %
             // to any chunking — no figure of the cost record itself tells them apart, the launch's own time does.
-            if (ctx->cost_fill > 0.0 && ctx->cost_fill < 0.85 && c < 4 && ctx->cost_gx == (unsigned)wg_x && ctx->cost_gy == (unsigned)wg_y8) c = 4;
+            // (Only where a chunk still has 64 samples and more: config 4's frame, 64 spp, fills 0.8 of the slots in its first launch
+            // too, and in four chunks of 16 samples it ran 8.05 ms instead of 7.17.)
+            if (ctx->cost_fill > 0.0 && ctx->cost_fill < 0.85 && c < 4 && p->sample_count >= 256 && ctx->cost_gx == (unsigned)wg_x && ctx->cost_gy == (unsigned)wg_y8) c = 4;
         }
         if (c > p->sample_count / min_chunk) c = p->sample_count / min_chunk;
         // A mesh launch that the rule leaves in ONE piece keeps full 8 x 8 tiles: the small tiles chosen above for launches of few
