@@ -404,6 +404,25 @@ def test_sample_chunks_extremes(srt, oracle):
     pt.close()
 
 
+@pytest.mark.parametrize("name,w,h,spp,more", [("Scene1", 640, 64, 65, 97), ("Scene_indirect", 320, 48, 100, 131), ("Scene3", 1920, 32, 257, 64)])
+def test_tapered_chunks_with_awkward_sample_counts(srt, oracle, name, w, h, spp, more):
+    """Sample-chunked launches end in half-size chunks (the launch's last workgroups, KernelParams.chunk_full): sample counts
+    that leave the full chunks, the half chunks and the last chunk all different (65 = 33 + 16 + 16, 257, a resumed frame whose
+    first_sample is not 1); at least two launches each, so that the second runs with the recorded costs' chunk count."""
+    pt, objs, n = _pt(srt, name, w, h)
+    for launch in range(2):
+        pt.render(spp=spp, bounces=6, seed=5, count_rays=True)
+        assert pt.stats().sample_chunks >= 2
+    ofb, oacc, orays = _oracle_frame(oracle, objs, n, w, h, spp=spp, bounces=6, seed=5)
+    assert pt.stats().rays == orays
+    assert np.array_equal(pt.accumulator().view(np.uint32), oacc.view(np.uint32)) and np.array_equal(pt.framebuffer(), ofb)
+    pt.render(spp=more, bounces=6, seed=5, first_sample=spp + 1, reset=False)
+    assert pt.stats().sample_chunks >= 2
+    ofb2, oacc2, _ = _oracle_frame(oracle, objs, n, w, h, spp=more, bounces=6, seed=5, first_sample=spp + 1, reset=False, accumulator=oacc)
+    assert np.array_equal(pt.accumulator().view(np.uint32), oacc2.view(np.uint32)) and np.array_equal(pt.framebuffer(), ofb2)
+    pt.close()
+
+
 def test_poll_while_busy_then_render_again(srt):
     """srt_poll on a running launch reports "not done" without poisoning the next call: HIP's not-ready
     status must not come back from hipGetLastError() as that launch's error (same for the internal poll
