@@ -811,6 +811,9 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
                     ctx->cost_fill = sum * 1e-5 / ((double)ms * ctx->cu_count * (ctx->mesh_image.n_tris > 0 ? 16.0 : 20.0));
                 else
                     (void)hipGetLastError();
+#ifdef SRT_DEV
+                if (getenv("SRT_DEBUG_CHUNKS")) fprintf(stderr, "recorded launch: %.3f ms, wave time %.1f wave-ms, dearest block %u ticks, fill %.3f\n", ms, sum * 1e-5, hi, ctx->cost_fill);
+#endif
             }
             const double scale = hi > lo ? (double)(NB - 1) / (double)(hi - lo) : 0.0;
             auto bucket = [&](uint32_t c) { return (NB - 1) - (int)((double)(c - lo) * scale); };
