@@ -8,7 +8,7 @@
 // it is MI355X-first and shares nothing with the reference's structure:
 //
 //   * one work-item = one pixel for set-up and output; wavefront (64 lanes) = 8x8 pixel tile;
-//     workgroup = 4 waves = 16x16 pixels; 128 VGPRs -> 4 waves per SIMD.
+//     workgroup = 4 waves = 16x16 pixels (dealt to the waves pixel by pixel); 85..95 VGPRs -> 5 waves per SIMD (mesh: 120, 4).
 //   * the flattened scene image (srt_scene_image.h) is staged ONCE per workgroup into LDS.
 //   * primary rays do not depend on the sample (no jitter, Raytracer.cpp:109-110): the primary
 //     hit is found once per pixel; pixels whose colour is sample-invariant finish immediately.
@@ -30,7 +30,10 @@
 //   * launches with few rows and many samples per pixel (a stripe of a multi-GPU frame) would have too few,
 //     too long workgroups: from 16 spp the tile of a wave shrinks (P.tile_h rows, MULTI hand-out), from 64
 //     spp the samples of a tile are split over several workgroups (DEFER) that store the colours as rows of
-//     a sample buffer, and fold_kernel folds them in sample order (HBM-bound, 16 B per traced sample).
+//     a sample buffer, and fold_kernel folds them in sample order (HBM-bound, 16 B per traced sample); the last chunks of a
+//     launch are half as long (the launch's tail).
+//   * the PROBE instantiation runs the same pool without touching the frame and counts its loop trips: the cost estimate behind
+//     the multi-GPU row split (srt_estimate_row_costs).
 //
 // Bit-exactness rules (the file is compiled with -ffp-contract=off; hipcc's default
 // correctly-rounded fp32 divide/sqrt stays on; fp32 denormals are not flushed):
@@ -38,7 +41,9 @@
 //   like Color's constructor (Common.hpp:253-262); comparisons keep their NaN behaviour
 //   (a > b ? a : b, never fmaxf).  Explicit FMAs appear only (a) in conservative filters, where
 //   any rounding is covered by the inflation proofs, (b) in srt_powf / rand_unit, where host and
-//   device execute the same fused operations or the result is verified exhaustively.
+//   device execute the same fused operations or the result is verified exhaustively, (c) in the short forms of the library's
+//   own sqrt / divide expansions (normalized(), div_window(): the library's operations minus its rescaling and fix-up steps
+//   where those are identities; srt_selftest_arith compares the two on the device).
 //   Winner updates are written as branch-free selects (see the note in closest_hit).
 #pragma once
 
