@@ -39,7 +39,8 @@
 // correctly-rounded fp32 divide/sqrt stays on; fp32 denormals are not flushed):
 //   every expression of the reference keeps its association; Color results go through clamp0()
 //   like Color's constructor (Common.hpp:253-262); comparisons keep their NaN behaviour
-//   (a > b ? a : b, never fmaxf).  Explicit FMAs appear only (a) in conservative filters, where
+//   (a > b ? a : b — fmaxf / fminf only in the box slab test, and only when the wave has seen that no operand can be a NaN).
+//   Explicit FMAs appear only (a) in conservative filters, where
 //   any rounding is covered by the inflation proofs, (b) in srt_powf / rand_unit, where host and
 //   device execute the same fused operations or the result is verified exhaustively, (c) in the short forms of the library's
 //   own sqrt / divide expansions (normalized(), div_window(): the library's operations minus its rescaling and fix-up steps
