@@ -1083,7 +1083,7 @@ static int run_pool_probe(srt_context* ctx, int max_bounces, uint32_t seed, std:
 struct ProbeWeights {
     // a pool step: its fixed part + what every step runs through per group of four uniform spheres / cluster bound / box / mesh root test
     double step = 700.0, step_ugroup = 70.0, step_cluster = 12.0, step_box = 45.0, step_mesh = 60.0;
-    double group = 660.0;          // four clustered spheres through the exact test for 64 items (carries the scatter, shuffles and merge of its round)
+    double group = 760.0;          // four clustered spheres through the exact test for 64 items (carries the scatter, shuffles and merge of its round)
     double node_round = 26.0, leaf_trip = 1300.0, mesh_phase = 65.0;  // BVH traversal (the leaf trips carry the memory round trips of the whole phase)
     double wave = 5830.0;          // per tile: staging, primary rays, ring — what every sample chunk of a real launch repeats
     double untraced_wave = 358.0;  // a tile with sample-independent pixels folds their colour sample by sample
