@@ -31,6 +31,12 @@ def test_partition_rows_cost_balanced(srt):
     assert all(a < b for a, b in bands) and all(bands[i][1] == bands[i + 1][0] for i in range(3))
     tot = [sum(cost[a:b]) for a, b in bands]
     assert max(tot) / (sum(tot) / 4) < 1.06
+    # the alignment bench.py and MultiGpuRenderer use (2 rows): boundaries even, balance no worse than with 8
+    bands2 = st.partition_rows(1080, 8, cost, align=2)
+    assert all(a % 2 == 0 for a, _ in bands2) and bands2[-1][1] == 1080
+    tot2 = [sum(cost[a:b]) for a, b in bands2]
+    tot8 = [sum(cost[a:b]) for a, b in st.partition_rows(1080, 8, cost, align=8)]
+    assert max(tot2) <= max(tot8) * 1.0001 and max(tot2) / (sum(tot2) / 8) < 1.03
     # degenerate: all cost in one row still gives every rank >= 1 row
     bands = st.partition_rows(16, 4, [0] * 15 + [1])
     assert all(b - a >= 1 for a, b in bands) and bands[-1][1] == 16
