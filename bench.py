@@ -19,13 +19,20 @@ Workloads (BASELINE.json `configs`, 1-based like SURVEY §8):
 
 Prints ONE JSON line on rank 0 and exits non-zero if an in-run parity check failed.  Extra objects:
   roofline       the bound that limits the kernel: fp32 VALU issue without FMA credit.
-                 `achieved` = algorithmic lane-ops per launch / kernel time.  For analytic scenes the
-                 lane-ops are the brute-force-equivalent count of the §8d formula (the kernel culls, so
-                 this is an algorithmic-throughput fraction); for mesh scenes they are COUNTED (BVH node
-                 and triangle tests per ray, profiles/mesh_counts.json).  `measured_valu_issue_frac` is
-                 the pipe utilisation from rocprofv3 counters (profiles/counters.json), `traffic` the
-                 HBM bytes per launch from the same file.
+                 `achieved` = EXECUTED lane-operations per launch / kernel time, and the executed work is COUNTED BY
+                 THE RUN ITSELF: one extra, untimed launch of the same shape with SRT_RENDER_COUNT_WORK returns what the
+                 kernel's loops did (pool steps, sphere / bound / box / BVH-child / triangle tests, srt_get_work_counts);
+                 bench.py prices every test with SURVEY §8d's constants (24 / 35 / 40 lane-ops per sphere / box /
+                 triangle test) plus three stated figures (VALU_MODEL below) and divides by the time and
+                 the peak.  Executed instructions cannot exceed the issue capacity, so `frac` <= 1.  `counted` holds
+                 the raw counts, so the fraction can be recomputed from the line alone.
+  algorithmic    (outside `roofline`) the brute-force-equivalent lane-ops of the §8d formula over the same time: what a
+                 kernel without culling and without the once-per-pixel primary hit would have had to execute —
+                 `speedup_vs_bruteforce` = that / executed.  Round 3 printed this as `roofline.frac` (1.31).
   roofline_hbm   the HBM view the metric's wording asks for (compulsory bytes / kernel time vs 8 TB/s).
+  readback       the frame's way into host memory (where the reference's frame ends: renderSurface->pixels,
+                 Raytracer.cpp:64,75): srt_read_framebuffer into pinned and pageable memory, `value_including_readback`,
+                 and a double-buffered loop that copies frame k while frame k + 1 renders.  Never in `value`.
   cpu_baseline   the oracle (CPU port of the reference loop) on this box's host cores, on a bounded
                  sample of the same workload; also used to assert parity in-run.
 """
@@ -45,6 +52,16 @@ HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s s
 VALU_PEAK_LANEOPS = 256 * 128 * 2.4e9      # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz, no FMA credit
 BAND_ALIGN = 2                             # rows: boundaries of the cost-balanced split (8 cost 2-3 points of balance at N = 8)
 NODE_OPS, TRI_OPS = 240, 40                # lane-ops per BVH node item (8 child boxes) / triangle test
+# What a counted unit of executed work costs in fp32 VALU lane-operations (= instructions x lanes; an FMA is ONE issue slot, like
+# every instruction, against a peak without FMA credit).  sphere / box / triangle are SURVEY §8d's constants — and the kernel's own
+# instruction counts for the candidate test of a sphere (24: srt_kernel.hip.h part1) and the slab test; the others are stated here
+# and derived in DESIGN.md §4.7: a cluster-bound test is 14 instructions (three differences, three 3-term FMA chains, the inflated
+# radius, compare, mask), a quantized BVH child box 21 (six byte conversions, six FMAs, max3 / min3, the culling compares), and
+# `step` is everything a pool step runs besides those tests — ray generation (four hash rounds, two normalisations), shading with
+# the environment's powf, the ordered fold, the task hand-out, the compaction and merge around the exact rounds, hit point and
+# normal — per lane and step, calibrated ONCE on config 2 as (SQ_INSTS_VALU - the priced tests) / pool steps from
+# profiles/r04/pmc_c2.json and checked against the counters of the other workloads (profiles/r04/valu_model.json).
+VALU_MODEL = {"sphere": 24, "box": 35, "triangle": 40, "bound": 14, "bvh_child": 21, "step": 760, "step_mesh": 860, "sample": 30}
 
 # BASELINE.json configs, 1-based.  mesh = tessellation of Scene1's big ball (224 -> 99,904 triangles)
 CONFIGS = {
@@ -67,6 +84,18 @@ def algorithmic_laneops_per_sample(rbar, n_sph, n_box, node_items=0.0, tri_tests
     """F = R*(24*N_sph + 35*N_box) + 60*R + 30 fp32 lane-ops per path-sample, plus — for
     mesh scenes — the COUNTED BVH work per sample (node items x 240 + triangle tests x 40)."""
     return rbar * (24 * n_sph + 35 * n_box) + 60 * rbar + 30 + node_items * NODE_OPS + tri_tests * TRI_OPS
+
+
+def executed_laneops(wc, samples, mesh):
+    """Lane-operations the launch EXECUTED, from its own loop counts (srt_work_counts as a dict) priced with VALU_MODEL:
+    every test count is lane-level and executed (a wave runs a loop trip for all 64 lanes), a pool step costs its fixed part for
+    64 lanes, every path-sample its accumulate / tone-map share.  None when the launch could not count."""
+    if not wc or not wc.get("valid"):
+        return None
+    m = VALU_MODEL
+    return (m["sphere"] * (wc["uniform_sphere_tests"] + wc["cluster_sphere_tests"]) + m["box"] * wc["box_tests"] + m["bound"] * wc["cluster_bound_tests"] +
+            m["bvh_child"] * wc["bvh_child_tests"] + m["triangle"] * wc["triangle_tests"] + (m["step_mesh"] if mesh else m["step"]) * 64 * wc["pool_steps"] +
+            m["sample"] * samples)
 
 
 def workload_key(scene, mesh, width, height, rows, spp, bounces):
@@ -226,8 +255,11 @@ def main():
         t_cal = time.perf_counter()
         row_cost = pt.estimate_row_costs(bounces, SEED)
         bands = stripes.partition_rows(H, n_parts, row_cost, align=BAND_ALIGN)
-        calibration = {"calibration_launches": 0, "probe_launches": 1, "calibration_ms": (time.perf_counter() - t_cal) * 1e3,
-                       "calibration": "none: srt_estimate_row_costs is one device-side probe — the path pool over a quarter of the pixels for the first 32 samples, counting loop trips, no timing; the same numbers on every rank"}
+        # (the probe IS a launch — a whole frame's pool over a quarter of the pixels for 32 samples, about 8 sample-frames of work on
+        # every rank — and it is outside the timed region: probe_ms says what it cost, value_including_probe_once what the
+        # run's rate is with it paid once, so the balanced and the equal split can be compared end to end)
+        calibration = {"calibration_launches": 1, "probe_launches": 1, "probe_ms": (time.perf_counter() - t_cal) * 1e3,
+                       "calibration": "srt_estimate_row_costs: one device-side probe launch per rank — the path pool over a quarter of the pixels for the frame's first 32 samples, counting loop trips, no timing; the same numbers on every rank, no collective"}
         rb, re = bands[share[0] if share else rank]
     elif share:
         bands = stripes.partition_rows(H, share[1])
@@ -244,25 +276,27 @@ def main():
     pt.wait()
 
     host_frame = torch.zeros((H, W), dtype=torch.int32) if rehearsal else None
+    # the padded gather's buffers, made once (stripes.GatherBuffers: the sending side is a view of the frame)
+    gather_frame = host_frame if rehearsal else frame
+    gather_buffers = stripes.GatherBuffers(gather_frame, bands, rank, world) if world > 1 and gather_method == "padded" else None
 
-    kernel_events = []  # (begin, end) HIP events on the launch stream around every TIMED step's srt_render, the gather outside
+    kernel_events = []  # (begin, end, gather end) HIP events on the launch stream around every TIMED step's srt_render and its gather
 
-    def step(count_rays=False, timed=False):
+    def step(count_rays=False, timed=False, count_work=False):
         if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             e0.record(stream)
-        pt.render(spp=spp, bounces=bounces, seed=SEED, first_sample=1, reset=True, rows=(rb, re), count_rays=count_rays)
+        pt.render(spp=spp, bounces=bounces, seed=SEED, first_sample=1, reset=True, rows=(rb, re), count_rays=count_rays, count_work=count_work)
         if timed:
             e1.record(stream)
-            kernel_events.append((e0, e1))
-        if world == 1:
-            return
-        if rehearsal:  # gloo cannot move device memory: stage through the host
-            stream.synchronize()
-            host_frame[rb:re].copy_(frame[rb:re])
-            stripes.gather_bands(host_frame, bands, rank, world, dist, method=gather_method)
-        else:
-            stripes.gather_bands(frame, bands, rank, world, dist, method=gather_method)
+        if world > 1:
+            if rehearsal:  # gloo cannot move device memory: stage through the host
+                stream.synchronize()
+                host_frame[rb:re].copy_(frame[rb:re])
+            stripes.gather_bands(gather_frame, bands, rank, world, dist, method=gather_method, buffers=gather_buffers)
+        if timed:
+            e2.record(stream)
+            kernel_events.append((e0, e1, e2))
 
     def fence():
         if world > 1:
@@ -296,13 +330,19 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    launch_ms_mean = sum(a.elapsed_time(b) for a, b in kernel_events) / len(kernel_events)  # this rank's srt_render launches only
+    launch_ms_mean = sum(a.elapsed_time(b) for a, b, _ in kernel_events) / len(kernel_events)  # this rank's srt_render launches only
+    gather_ms_mean = sum(b.elapsed_time(c) for _, b, c in kernel_events) / len(kernel_events)  # ... and its gathers (stream time behind the kernel)
     k_ms = stream_ms if world == 1 else launch_ms_mean
+    st_timed = pt.stats()  # the shape of the last timed launch
 
-    # rays per sample (deterministic): one extra, untimed launch with the counter on
-    step(count_rays=True)
+    # rays per sample and the executed work (both deterministic): one extra, untimed launch of the same shape with the counters on
+    step(count_rays=True, count_work=True)
     st_last = pt.stats()
     rays = st_last.rays
+    wc = pt.work_counts().as_dict()
+    shape = {"tile_rows": int(st_last.tile_rows), "grid_layers": int(st_last.sample_chunks), "chunk_samples": int(st_last.chunk_samples),
+             "shape_source": "work record of the band's first launch" if st_last.shape_source else "static rule (request and grid)",
+             "same_as_timed_launches": (st_last.tile_rows, st_last.sample_chunks, st_last.chunk_samples) == (st_timed.tile_rows, st_timed.sample_chunks, st_timed.chunk_samples)}
     # sample-chunked launch (srt_stats.sample_chunks > 1): the colours of every TRACED sample go through HBM once (16 B
     # written by pathtrace_kernel, 16 B read by fold_kernel).  Traced pixels = pixels whose primary ray hits something:
     # a 1-spp / 1-bounce launch casts exactly one extra ray for each of them.
@@ -317,13 +357,16 @@ def main():
     total_samples = (W * (re - rb) if share else W * H) * spp
     value = total_samples * args.steps / dt
 
+    ex_local = executed_laneops(wc, local_samples, bool(n_tri))
+    mine = [k_ms, float(rays), float(local_samples), float(ex_local if ex_local is not None else -1.0), gather_ms_mean,
+            float(wc["pool_steps"]), float(st_last.sample_chunks), float(st_last.tile_rows)]
     if world > 1:
-        info = torch.tensor([k_ms, float(rays), float(local_samples)], dtype=torch.float64, device=cdev)
+        info = torch.tensor(mine, dtype=torch.float64, device=cdev)
         allinfo = [torch.zeros_like(info) for _ in range(world)]
         dist.all_gather(allinfo, info)
         per_rank = [[float(x) for x in t.tolist()] for t in allinfo]
     else:
-        per_rank = [[k_ms, float(rays), float(local_samples)]]
+        per_rank = [mine]
 
     # the gathered multi-rank frame must equal a single-device render of the whole frame
     stripe_parity = None
@@ -339,40 +382,119 @@ def main():
             stripe_parity = bool(np.array_equal(chk.framebuffer(), gathered))
             chk.close()
 
+    # ---- the frame's way into host memory (N = 1): where the reference's frame ends (renderSurface->pixels, Raytracer.cpp:64,75).
+    # After the timed region, never in `value`: srt_read_framebuffer into pinned and into pageable memory, and a double-buffered
+    # loop — frame k is copied on a second stream while frame k + 1 renders into the other framebuffer (srt_bind_output does
+    # not wait) — the way a host that blits every frame would run it.
+    readback = None
+    if world == 1 and rank == 0:
+        import numpy as np
+
+        step_ms = dt / args.steps * 1e3
+        pinned = torch.empty((H, W), dtype=torch.int32).pin_memory()
+        pageable = np.empty((H, W), dtype=np.uint32)
+
+        def read_ms(ptr, reps=5):
+            best = None
+            for _ in range(reps):
+                t = time.perf_counter()
+                pt._ck(pt.L.srt_read_framebuffer(pt._h, C.c_void_p(ptr), W * 4, rb, re))
+                e = (time.perf_counter() - t) * 1e3
+                best = e if best is None else min(best, e)
+            return best
+
+        pin_ms = read_ms(pinned.data_ptr() + rb * W * 4)
+        page_ms = read_ms(pageable.ctypes.data + rb * W * 4)
+        frames = [frame, torch.zeros_like(frame)]
+        hosts = [pinned, torch.empty((H, W), dtype=torch.int32).pin_memory()]
+        copy_stream = torch.cuda.Stream(dev)
+        rendered = [torch.cuda.Event() for _ in range(2)]
+        copied = [torch.cuda.Event() for _ in range(2)]
+        n_ov = max(args.steps, 4)
+
+        def overlapped(n):
+            for k in range(n):
+                i = k & 1
+                if k >= 2:
+                    stream.wait_event(copied[i])  # the copy of frame k - 2 has left this framebuffer
+                pt.bind_output(d_framebuffer=frames[i].data_ptr())
+                pt.render(spp=spp, bounces=bounces, seed=SEED, first_sample=1, reset=True, rows=(rb, re))
+                rendered[i].record(stream)
+                copy_stream.wait_event(rendered[i])
+                with torch.cuda.stream(copy_stream):
+                    hosts[i][rb:re].copy_(frames[i][rb:re], non_blocking=True)
+                    copied[i].record(copy_stream)
+
+        overlapped(2)
+        torch.cuda.synchronize(dev)
+        t_ov = time.perf_counter()
+        overlapped(n_ov)
+        torch.cuda.synchronize(dev)
+        ov_ms = (time.perf_counter() - t_ov) * 1e3 / n_ov
+        same = bool(torch.equal(hosts[0][rb:re], hosts[1][rb:re]) and torch.equal(hosts[0][rb:re], frames[0][rb:re].cpu()))
+        pt.bind_output(d_framebuffer=frame.data_ptr())
+        readback = {
+            "frame_to_host_ms": pin_ms, "frame_to_host_ms_pageable": page_ms, "bytes": W * (re - rb) * 4,
+            "how": "srt_read_framebuffer (synchronous hipMemcpy2D) of this launch's rows into pinned / pageable host memory, best of 5, after the timed region",
+            "fraction_of_a_step": pin_ms / step_ms,
+            "value_including_readback": total_samples / ((step_ms + pin_ms) * 1e-3),
+            "ms_per_step_with_overlapped_readback": ov_ms,
+            "value_with_overlapped_readback": total_samples / (ov_ms * 1e-3),
+            "overlapped_how": "%d steps, two framebuffers: frame k is copied device-to-pinned on a second stream while frame k + 1 renders (srt_bind_output does not wait); wall clock / steps" % n_ov,
+            "overlapped_frames_identical": same,
+        }
+
+    # ---- the first launch of a frame with WARM clocks (N = 1): a fresh context — no recorded costs, the dispatch order estimated on
+    # the device — renders the same frame right after the timed region; next to kernel_ms_cold_first_launch (the run's very first
+    # step, which also pays the clock ramp of a GPU that was idle a moment ago) this separates what the missing record costs
+    # from what the power management does.  Event pair on the stream around srt_render, order estimate included.
+    warm_first_ms = None
+    if world == 1 and rank == 0:
+        fresh = new_tracer()
+        fresh.bind_output(d_framebuffer=frames[1].data_ptr())
+        fresh.set_stream(stream.cuda_stream)
+        fresh.render(spp=1, bounces=1, seed=SEED, first_sample=1, reset=True, rows=(0, min(8, H)))  # (code objects are loaded per process, not per context; kept symmetrical with the run's priming launch)
+        for _ in range(3):
+            pt.render(spp=spp, bounces=bounces, seed=SEED, first_sample=1, reset=True, rows=(rb, re))
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record(stream)
+        fresh.render(spp=spp, bounces=bounces, seed=SEED, first_sample=1, reset=True, rows=(rb, re))
+        f1.record(stream)
+        torch.cuda.synchronize(dev)
+        warm_first_ms = f0.elapsed_time(f1)
+        fresh.close()
+
     out = None
     if rank == 0:
         rbar = sum(p[1] for p in per_rank) / sum(p[2] for p in per_rank)
         key = workload_key(cfg["scene"], cfg["mesh"], W, H, (rb, re), spp, bounces)
         all_counters = load_json(os.path.join(ROOT, "profiles", "counters.json"))
-        all_mesh_counts = load_json(os.path.join(ROOT, "profiles", "mesh_counts.json")) if n_tri else {}
         counters = all_counters.get(key, {}) if world == 1 else {}
         rank_rows = [tuple(bands[i]) if not share else (rb, re) for i in range(len(per_rank))]
-        # lane-ops of every rank's launch (SURVEY §8d formula with that rank's own rays per sample; mesh scenes: + the counted
-        # BVH work of that rank's band from profiles/mesh_counts.json), then: one rank -> its launch; N ranks -> the sum of all
-        # ranks' lane-ops over the SLOWEST rank's launch time against N GPUs' peak, with every rank's own fraction in per_rank
-        uncounted = False
-        rank_ops, rank_f = [], []
-        for (k_i, rays_i, samples_i), rows_i in zip(per_rank, rank_rows):
-            mc = all_mesh_counts.get(workload_key(cfg["scene"], cfg["mesh"], W, H, rows_i, spp, bounces), {}) if n_tri else {}
-            uncounted = uncounted or (bool(n_tri) and not mc)
-            f_i = algorithmic_laneops_per_sample(rays_i / samples_i, n_sph, n_box, mc.get("node_items_per_sample", 0.0), mc.get("triangle_tests_per_sample", 0.0))
-            rank_f.append(f_i)
-            rank_ops.append(f_i * samples_i)
+        # EXECUTED lane-ops of every rank's launch, counted by that rank's own counting launch (executed_laneops); one rank -> its
+        # launch; N ranks -> the sum over the SLOWEST rank's launch time against N GPUs' peak, every rank's own fraction in per_rank.
+        # Next to it, outside the roofline: the brute-force-equivalent count of the SURVEY §8d formula with that rank's own rays per
+        # sample (mesh scenes: the BVH work as counted) — what a kernel without culling would have had to execute.
+        counted_ok = all(p[3] >= 0 for p in per_rank)
+        rank_ex = [p[3] if p[3] >= 0 else 0.0 for p in per_rank]
+        bvh_ops = VALU_MODEL["bvh_child"] * wc["bvh_child_tests"] + VALU_MODEL["triangle"] * wc["triangle_tests"] if n_tri else 0.0
+        rank_bf = []
+        for (k_i, rays_i, samples_i, *_rest) in per_rank:
+            rank_bf.append(algorithmic_laneops_per_sample(rays_i / samples_i, n_sph, n_box) * samples_i)
         slowest_ms = max(p[0] for p in per_rank)
-        achieved_valu = sum(rank_ops) / (slowest_ms * 1e-3)
+        achieved_valu = sum(rank_ex) / (slowest_ms * 1e-3)
+        bruteforce_valu = (sum(rank_bf) + (bvh_ops if world == 1 else 0.0)) / (slowest_ms * 1e-3)
         peak_valu = VALU_PEAK_LANEOPS * len(per_rank)
         abytes = algorithmic_bytes(W, re - rb, n_obj, resume=False)
         abytes += 32 * traced_samples  # sample-chunked launch: + 16 B written and 16 B read per traced sample (the fold's stream)
         achieved_gbs = abytes / (k_ms * 1e-3) / 1e9
-        if uncounted:
-            kind = "UNCOUNTED: no profiles/mesh_counts.json entry for this workload; the BVH work is missing from `achieved`"
-        elif n_tri:
-            kind = "counted: analytic part by the SURVEY §8d formula + BVH node items x %d + triangle tests x %d (profiles/mesh_counts.json)" % (NODE_OPS, TRI_OPS)
-        else:
-            kind = "brute-force-equivalent lane-ops of the SURVEY §8d formula (the kernel culls: algorithmic throughput, not pipe utilisation)"
+        kind = ("executed lane-ops COUNTED by this run (one untimed launch of the same shape with SRT_RENDER_COUNT_WORK; `counted`) priced with "
+                "`valu_model`: tests x the SURVEY §8d constants + the stated per-bound / per-BVH-child / per-step figures (DESIGN.md §4.7)")
+        if not counted_ok:
+            kind = "UNCOUNTED: a launch whose scene image lives in HBM keeps no loop counts; `achieved` is 0"
         if world > 1:
-            kind += "; N = %d: sum of all ranks' lane-ops / the slowest rank's launch time, peak = %d GPUs" % (world, world)
-        # pipe utilisation: computed INSIDE the counter pass (its own SQ_INSTS_VALU over its own launch time), copied from profiles
+            kind += "; N = %d: sum of all ranks' executed lane-ops / the slowest rank's launch time, peak = %d GPUs" % (world, world)
+        # pipe utilisation as rocprofv3 saw it: computed INSIDE the counter pass (its own SQ_INSTS_VALU over its own launch time), copied from profiles
         measured_issue = counters.get("valu_issue_frac")
         custom = any(getattr(args, k) is not None for k in ("scene", "width", "height", "spp", "bounces", "mesh"))
         what = "custom workload (config %d with overrides)" % cfg_id if custom else "config %d" % cfg_id
@@ -407,6 +529,9 @@ def main():
                                  "dist.gather over RCCL" if gather_method == "gather" else "RCCL gather (%s)" % gather_method),
                 "bands": bands if not share else [[rb, re]],
                 "rays_per_sample": rbar,
+                # what srt_render chose for this rank's launch (srt_stats): a function of the request, the grid, the CU count and the
+                # band's recorded loop counts — the same in every run
+                "launch_shape": shape,
             },
             "roofline": {
                 "bound": "valu",
@@ -421,10 +546,14 @@ def main():
                                     if world == 1 else "the SLOWEST rank's mean over the HIP event pairs around each timed step's srt_render (the gather outside); all ranks in per_rank",
                 "kernel_ms_last_timed_launch": last_launch_ms,
                 "kernel_ms_cold_first_launch": cold_ms,
+                "kernel_ms_first_launch_warm_clocks": warm_first_ms,
                 "peak_note": "%sfp32 VALU without FMA credit: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (contraction is forbidden by the bit-exactness contract)" %
                              ("%d GPUs x " % world if world > 1 else ""),
                 "achieved_kind": kind,
-                "algorithmic_laneops_per_sample": sum(rank_ops) / sum(p[2] for p in per_rank),
+                "counted": wc if world == 1 else {"note": "rank 0's counts; every rank's executed lane-ops in per_rank", **wc},
+                "valu_model": VALU_MODEL,
+                "executed_laneops_per_sample": sum(rank_ex) / sum(p[2] for p in per_rank),
+                "pool_lane_efficiency": (rays - W * (re - rb)) / (64.0 * wc["pool_steps"]) if wc.get("pool_steps") else None,
                 "rays_per_sample": rbar,
                 "measured_valu_issue_frac": measured_issue,
                 "measured_valu_issue_frac_note": "from profiles/counters.json, NOT from this run: SQ_INSTS_VALU x 64 / the launch time of the rocprofv3 pass "
@@ -432,6 +561,14 @@ def main():
                 "measured_valu_issue_frac_grbm": counters.get("valu_issue_frac_grbm"),
                 "measured_pass_launch_ms": counters.get("valu_issue_pass_launch_ms"),
                 "measured_source": counters.get("source"),
+            },
+            "algorithmic": {
+                "bruteforce_equivalent_tflops": bruteforce_valu / 1e12,
+                "speedup_vs_bruteforce": bruteforce_valu / achieved_valu if achieved_valu else None,
+                "laneops_per_sample": (sum(rank_bf) + (bvh_ops if world == 1 else 0.0)) / sum(p[2] for p in per_rank),
+                "note": "SURVEY §8d formula F = R(24 N_sph + 35 N_box) + 60 R + 30 with this run's rays per sample%s: what a scan of every primitive for every ray "
+                        "would execute in the same time; NOT a utilisation (it passes the peak where the kernel culls and shares the primary hit among a pixel's samples)" %
+                        (" + the counted BVH work" if n_tri else ""),
             },
             "roofline_hbm": {
                 "bound": "hbm",
@@ -444,11 +581,19 @@ def main():
                 "note": "compulsory bytes only (20 B/pixel + scene%s); not the limiting resource" %
                         (" + 32 B per traced sample of the chunked launch's sample buffer" if chunks > 1 else ""),
             },
-            "per_rank": [{"kernel_ms": p[0], "rays_per_sample": p[1] / p[2], "rows": list(rank_rows[i]), "algorithmic_laneops": rank_ops[i],
-                          "frac": rank_ops[i] / (p[0] * 1e-3) / VALU_PEAK_LANEOPS} for i, p in enumerate(per_rank)],
+            "per_rank": [{"kernel_ms": p[0], "gather_ms": p[4] if world > 1 else None, "rays_per_sample": p[1] / p[2], "rows": list(rank_rows[i]),
+                          "executed_laneops": rank_ex[i], "frac": rank_ex[i] / (p[0] * 1e-3) / VALU_PEAK_LANEOPS, "pool_steps": p[5],
+                          "grid_layers": int(p[6]), "tile_rows": int(p[7])} for i, p in enumerate(per_rank)],
         }
+        if readback:
+            out["readback"] = readback
         if calibration:
             out["config"].update(calibration)
+            out["config"]["value_including_probe_once"] = total_samples * args.steps / (dt + calibration["probe_ms"] * 1e-3)
+        if world > 1:
+            # the N > 1 step = this rank's launch + the one gather: both halves, as the stream saw them (event pairs)
+            out["gather_ms"] = max(p[4] for p in per_rank)
+            out["gather_ms_note"] = "stream time between the end of a rank's kernel and the end of its part of the gather (rank 0: + the unpack copies), mean over the timed steps, max over ranks; unverified on > 1 GPU until the driver's run"
         if world > 1 or share:
             # what every rank's launch of this split took when the ranks were run one after the other on ONE GPU (kernel times
             # only, no gather; tools/emulate_ranks.py, committed as profiles/emulated_ranks.json) — both splits, so that the

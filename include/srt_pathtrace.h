@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SRT_ABI_VERSION 5
+#define SRT_ABI_VERSION 6
 
 typedef enum srt_status {
     SRT_OK = 0,
@@ -122,6 +122,7 @@ typedef struct srt_camera {
 #define SRT_RENDER_COUNT_RAYS 2u  /* fill srt_stats.rays (costs one atomic per wave)       */
 #define SRT_RENDER_PREVIEW 4u     /* SIMPLEDRAW == true: the one-ray preview shader (:147-160)
                                      instead of the path-traced branch (:162-185)           */
+#define SRT_RENDER_COUNT_WORK 8u  /* count what the launch's loops execute (srt_get_work_counts); same image, a little slower */
 
 /* One render call = sample_count successive "frames" of the reference's loop over a
  * band of memory rows, all on the device, accumulator kept in registers in between
@@ -153,9 +154,36 @@ typedef struct srt_stats {
     uint64_t path_samples;  /* W_band * H_band * sample_count of the last render */
     float kernel_ms;        /* HIP-event time of the last render's kernel(s) on its stream */
     uint32_t sample_chunks; /* 1: one kernel traced and folded every sample; n > 1: the samples of a tile were split
-                               over n workgroups that stored the colours, and a second, streaming kernel folded
+                               over n workgroups (grid layers) that stored the colours, and a second, streaming kernel folded
                                them in order (16 B written + 16 B read per traced sample on top of the 20 B/pixel) */
+    /* The launch shape srt_render chose (ABI 6).  It is a function of the request, the grid, the device's CU count and — from the
+     * second launch of a band on — the loop counts the band's first launch recorded; never of a clock: the same calls give the
+     * same shape in every run. */
+    uint32_t tile_rows;     /* rows of a wavefront's pixel tile: 8, or 4 / 2 / 1 for launches of few workgroups */
+    uint32_t chunk_samples; /* samples per full-size sample chunk (the last layers may hold half as many); 0: not chunked */
+    uint32_t shape_source;  /* 0: the static rule (request and grid only); 1: the band's recorded block work as well */
 } srt_stats;
+
+/* What the kernels of ONE render executed (SRT_RENDER_COUNT_WORK), counted by the launch itself in wave-uniform loop counters.
+ * "tests" are lane-level and EXECUTED: a wavefront runs every trip of these loops for all 64 lanes whatever they carry, so a
+ * trip counts 64 tests; cluster_items counts the useful ones of the exact rounds.  Not part of the reference's interface; it is
+ * what bench.py prices its roofline line from. */
+typedef struct srt_work_counts {
+    uint32_t valid;                /* 0: this launch could not count (scene image too large for LDS); all fields 0 */
+    uint32_t reserved;
+    uint64_t waves;                /* wavefronts that ran a tile (each stages the scene and traces 64 primary rays) */
+    uint64_t pool_steps;           /* wave-level steps of the path pool: one bounce for up to 64 paths */
+    uint64_t closest_hit_calls;    /* GetClosestObject at wave level: pool steps + the tiles' primary rays */
+    uint64_t uniform_sphere_tests; /* Sphere::Raytrace, spheres every ray is tested against            (Object.hpp:104-141) */
+    uint64_t cluster_bound_tests;  /* conservative cluster-bound tests (no counterpart in the reference: the culling filter) */
+    uint64_t cluster_sphere_tests; /* Sphere::Raytrace, clustered spheres, in the exact rounds (64 per group of four and round) */
+    uint64_t cluster_items;        /* (ray, cluster) pairs that passed the bounds: the rounds' useful lanes */
+    uint64_t box_tests;            /* Box::Raytrace                                                    (Object.hpp:173-233) */
+    uint64_t bvh_child_tests;      /* EXTENSION: quantized child boxes of BVH nodes */
+    uint64_t triangle_tests;       /* EXTENSION: Moller-Trumbore */
+    uint64_t bvh_node_rounds;      /* EXTENSION: wave-level node rounds of the traversal */
+    uint64_t mesh_phases;          /* EXTENSION: wave-level traversal phases */
+} srt_work_counts;
 
 typedef struct srt_context srt_context;
 
@@ -187,7 +215,10 @@ int srt_set_camera(srt_context* ctx, const srt_camera* camera);
 /* Launch on this hipStream_t instead of the handle's own stream (NULL = own stream). */
 int srt_set_stream(srt_context* ctx, void* hip_stream);
 /* Render into caller-provided DEVICE buffers (e.g. a torch tensor's data_ptr) instead of
- * the handle's own: framebuffer = W*H uint32, accumulator = W*H float4. NULL = own. */
+ * the handle's own: framebuffer = W*H uint32, accumulator = W*H float4. NULL = own.  Takes effect for the
+ * calls that follow and does not wait: renders already enqueued keep the buffers they were given (the caller
+ * keeps those alive until they finish) — so frame k + 1 can render into a second framebuffer while frame k
+ * is copied to the host. */
 int srt_bind_output(srt_context* ctx, void* d_framebuffer, void* d_accumulator);
 int srt_device_framebuffer(srt_context* ctx, void** d_ptr);
 int srt_device_accumulator(srt_context* ctx, void** d_ptr);
@@ -199,6 +230,8 @@ int srt_render(srt_context* ctx, const srt_render_params* params);
 int srt_wait(srt_context* ctx);             /* block until the last render finished */
 int srt_poll(srt_context* ctx, int* done);  /* *done = 1 when finished              */
 int srt_get_stats(srt_context* ctx, srt_stats* out);  /* waits for the last render */
+/* The loop counts of the last render, which must have had SRT_RENDER_COUNT_WORK set (else SRT_ERR_STATE).  Waits. */
+int srt_get_work_counts(srt_context* ctx, srt_work_counts* out);
 
 /* Picking (Raytracer.cpp:525-541): GetClosestObject(camera.position, GetRayDirection(camera, x, y))
  * with y in SCENE rows (the reference flips the mouse y first, :532).  *object_index = list
@@ -224,6 +257,10 @@ int srt_write_accumulator(srt_context* ctx, const float* src_rgba);
  * width and height.  (Across PROCESSES the same gather is one RCCL collective:
  * software-raytracer_amd/stripes.py, bench.py --gpus N.) */
 int srt_gather_band(srt_context* dst, srt_context* src, int row_begin, int row_end);
+/* Which way `src`'s last srt_gather_band went, as text: the same device, a peer copy with peer access enabled (hipDeviceCanAccessPeer
+ * is asked once per pair of devices), or a copy the runtime had to stage.  The cross-device ways have never run on this project's
+ * one-GPU boxes; this is how the first multi-GPU run reports what it did.  The pointer stays valid until src is destroyed. */
+const char* srt_gather_path(const srt_context* src);
 /* Relative cost of every MEMORY row of the frame for the current scene and camera (row_costs[height], arbitrary
  * units), from a device-side probe: the path-trace kernel's own path pool, run over a quarter of the pixels for the
  * frame's first 32 samples, COUNTING what its loops do (pool steps, exactly tested sphere groups, BVH rounds, per-tile

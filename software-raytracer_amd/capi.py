@@ -15,16 +15,16 @@ _LIB = os.path.join(_PKG, "libsrt_pathtrace.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_OOM = range(6)
 OBJ_NONE, OBJ_SPHERE, OBJ_BOX, OBJ_MESH = 0, 1, 2, 3
-RENDER_RESET, RENDER_COUNT_RAYS, RENDER_PREVIEW = 1, 2, 4
-ABI_VERSION = 5
+RENDER_RESET, RENDER_COUNT_RAYS, RENDER_PREVIEW, RENDER_COUNT_WORK = 1, 2, 4, 8
+ABI_VERSION = 6
 
 # every symbol include/srt_pathtrace.h declares (tests check the library exports them all)
 EXPORTS = [
     "srt_abi_version", "srt_device_count", "srt_create", "srt_destroy", "srt_last_error",
     "srt_set_scene", "srt_set_meshes", "srt_set_environment", "srt_environment_default", "srt_set_camera",
     "srt_set_stream", "srt_bind_output", "srt_device_framebuffer", "srt_device_accumulator",
-    "srt_render", "srt_wait", "srt_poll", "srt_get_stats", "srt_pick", "srt_read_framebuffer",
-    "srt_read_accumulator", "srt_write_accumulator", "srt_gather_band", "srt_estimate_row_costs",
+    "srt_render", "srt_wait", "srt_poll", "srt_get_stats", "srt_get_work_counts", "srt_pick", "srt_read_framebuffer",
+    "srt_read_accumulator", "srt_write_accumulator", "srt_gather_band", "srt_gather_path", "srt_estimate_row_costs",
     "srt_selftest_arith",
 ]
 
@@ -101,7 +101,18 @@ class RenderParams(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("path_samples", C.c_uint64), ("kernel_ms", C.c_float), ("sample_chunks", C.c_uint32)]
+    _fields_ = [("rays", C.c_uint64), ("path_samples", C.c_uint64), ("kernel_ms", C.c_float), ("sample_chunks", C.c_uint32),
+                ("tile_rows", C.c_uint32), ("chunk_samples", C.c_uint32), ("shape_source", C.c_uint32)]
+
+
+class WorkCounts(C.Structure):
+    """srt_work_counts: what one render's kernels executed (SRT_RENDER_COUNT_WORK)."""
+    _fields_ = [("valid", C.c_uint32), ("reserved", C.c_uint32)] + [(n, C.c_uint64) for n in (
+        "waves", "pool_steps", "closest_hit_calls", "uniform_sphere_tests", "cluster_bound_tests", "cluster_sphere_tests",
+        "cluster_items", "box_tests", "bvh_child_tests", "triangle_tests", "bvh_node_rounds", "mesh_phases")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
 
 
 def lib_path():
@@ -173,16 +184,19 @@ def open_library(path):
     L.srt_wait.argtypes = [ctx]
     L.srt_poll.argtypes = [ctx, C.POINTER(C.c_int)]
     L.srt_get_stats.argtypes = [ctx, C.POINTER(Stats)]
+    L.srt_get_work_counts.argtypes = [ctx, C.POINTER(WorkCounts)]
     L.srt_pick.argtypes = [ctx, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.srt_read_framebuffer.argtypes = [ctx, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
     L.srt_read_accumulator.argtypes = [ctx, C.POINTER(C.c_float)]
     L.srt_write_accumulator.argtypes = [ctx, C.POINTER(C.c_float)]
     L.srt_gather_band.argtypes = [ctx, ctx, C.c_int, C.c_int]
+    L.srt_gather_path.argtypes = [ctx]
+    L.srt_gather_path.restype = C.c_char_p
     L.srt_estimate_row_costs.argtypes = [ctx, C.c_int, C.c_uint32, C.POINTER(C.c_float)]
     L.srt_selftest_arith.argtypes = [C.c_int, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name != "srt_last_error":
+        if name not in ("srt_last_error", "srt_gather_path"):
             fn.restype = C.c_int
     return L
 
@@ -267,9 +281,10 @@ class PathTracer:
 
     # ---- hot path --------------------------------------------------------------------
     def render(self, *, spp=1, bounces=4, seed=0, first_sample=1, reset=True, rows=None, count_rays=False,
-               preview=False, steps=1, stripe_width=0, selected=-1):
+               preview=False, steps=1, stripe_width=0, selected=-1, count_work=False):
         rb, re = rows if rows is not None else (0, self.height)
-        flags = (RENDER_RESET if reset else 0) | (RENDER_COUNT_RAYS if count_rays else 0) | (RENDER_PREVIEW if preview else 0)
+        flags = ((RENDER_RESET if reset else 0) | (RENDER_COUNT_RAYS if count_rays else 0) | (RENDER_PREVIEW if preview else 0) |
+                 (RENDER_COUNT_WORK if count_work else 0))
         p = RenderParams(rb, re, first_sample, spp, bounces, seed, flags, steps, stripe_width, selected)
         self._ck(self.L.srt_render(self._h, C.byref(p)))
 
@@ -291,6 +306,12 @@ class PathTracer:
         s = Stats()
         self._ck(self.L.srt_get_stats(self._h, C.byref(s)))
         return s
+
+    def work_counts(self):
+        """srt_get_work_counts: the loop counts of the last render (it must have had count_work=True)."""
+        w = WorkCounts()
+        self._ck(self.L.srt_get_work_counts(self._h, C.byref(w)))
+        return w
 
     # ---- buffers ---------------------------------------------------------------------
     def framebuffer(self, rows=None):
@@ -318,6 +339,10 @@ class PathTracer:
     def gather_band_from(self, src, rows):
         """srt_gather_band: memory rows `rows` of PathTracer `src`'s framebuffer into this one's (device to device)."""
         self._ck(self.L.srt_gather_band(self._h, src._h, int(rows[0]), int(rows[1])))
+
+    def gather_path(self):
+        """srt_gather_path: which way this tracer's last band went in gather_band_from (text)."""
+        return (self.L.srt_gather_path(self._h) or b"").decode()
 
     def device_framebuffer_ptr(self):
         p = C.c_void_p()

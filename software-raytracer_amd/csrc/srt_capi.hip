@@ -28,6 +28,9 @@ thread_local char g_create_error[512] = "";
 // Tuning switches.  The shipped library has none: every value below is a constant.  A development build
 // (make -C software-raytracer_amd/csrc dev -> libsrt_pathtrace_dev.so, -DSRT_DEV) reads them from the
 // environment for in-process A/B timing (tests/ab_bench.py); all settings produce identical bits.
+#ifndef SRT_FILL_MIN
+#define SRT_FILL_MIN 0.85  // mesh launches: simulated fill of the chip's workgroup slots below which a launch of >= 256 spp is cut into four sample chunks
+#endif
 #ifndef SRT_ORDER_MIN_WG
 #define SRT_ORDER_MIN_WG 256  // fewest blocks of tiles for which a launch records costs and is dispatched in cost order (round 3: 512 -> 256,
                               // the 48..64-row bands of a cost-balanced 8-rank 1080p frame: -4..-5 %)
@@ -98,6 +101,7 @@ struct srt_context {
     uint32_t* d_fb = nullptr;
     float4* d_acc = nullptr;
     unsigned long long* d_rays = nullptr;
+    unsigned long long* d_work = nullptr;  // SRT_RENDER_COUNT_WORK: the launch's loop counts (srt::TALLY_ALL words)
     int* d_pick = nullptr;
     int last_pick[4] = {0, 0, 0, 0};  // list index, distance bits, primitive id, normal.z bits (debug)
 
@@ -125,16 +129,22 @@ struct srt_context {
     unsigned order_gx = 0, order_gy = 0;  // grid the order in d_wg_order was made for (0 = none)
     unsigned rec_gx = 0, rec_gy = 0;      // grid of the recording in flight
     bool recording = false;               // a cost copy is in flight (ev_cost)
+    bool rec_has_work = false;            // ... and its second half holds the blocks' work (the recording launch was a TALLY instantiation)
+    int work_layout[4] = {0, 0, 0, 0};    // of the last launch: uniform spheres, clusters, spheres per cluster, boxes (srt_get_work_counts)
     bool order_stale = true;              // scene / camera changed since the costs were recorded
-    double cost_fill = 0.0;               // recorded wave time / (the recorded launch's time x resident waves), 0: unknown
-    double cost_sum = 0.0;                // of the last recorded block costs (0: none), their maximum and their grid:
-    uint32_t cost_max = 0;                //   the dearest block: how uneven the blocks are decides the number of sample chunks
+    // the launch-shape record (round 4): every block's WORK as the recording launch counted it — loop trips under the balance
+    // probe's weights, not times — so the sample-chunk rule is a deterministic function of scene, camera, band and call history
+    std::vector<uint32_t> work;           // per block of the recorded grid, sorted by decreasing work (what the fill simulation walks)
+    double work_sum = 0.0;                // of the record (0: none), its maximum and its grid:
+    uint32_t work_max = 0;                //   the dearest block: how uneven the blocks are decides the number of sample chunks
     unsigned cost_gx = 0, cost_gy = 0;
     int band_y0 = -1, band_rows = -1;     // the row band the order, the recording and the cost figures above belong to
     bool estimate_stale = true;           // the scene changed since the order was last estimated on the device
     bool order_disabled = false;          // buffers for the feedback could not be allocated
     hipEvent_t ev_cost = nullptr, ev_order = nullptr, ev_gather = nullptr;
-    unsigned long long peer_enabled = 0;  // srt_gather_band: destination devices this context's device has peer access enabled for
+    unsigned long long peer_asked = 0;    // srt_gather_band: destination devices this context has asked hipDeviceCanAccessPeer about (once per pair)
+    unsigned long long peer_direct = 0;   // ... and those it may reach directly (peer access enabled)
+    char gather_path[160] = "no gather yet";  // which way this context's last srt_gather_band went (srt_gather_path)
 
     srt_environment env;
     HostCamera camera;
@@ -143,6 +153,9 @@ struct srt_context {
     uint64_t pending_samples = 0;
     uint32_t pending_chunks = 1;
     bool count_rays = false;
+    bool count_work = false, count_work_valid = false;
+    uint32_t pending_tile_rows = 8, pending_chunk_samples = 0, pending_shape_source = 0;
+    srt_work_counts work_counts{};
     int lds_limit_bytes = 64 * 1024;
     int cu_count = 256;
     bool scene_in_lds[2] = {true, true};  // per scene image: does it fit into LDS next to the scratch?
@@ -248,6 +261,7 @@ int srt_create(int device, int width, int height, srt_context** out) {
     if ((e = hipMalloc((void**)&ctx->d_acc_own, px * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc accumulator");
     if ((e = hipMalloc((void**)&ctx->d_rays, sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc counter");
     if ((e = hipMalloc((void**)&ctx->d_pick, 4 * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc pick");
+    if ((e = hipMalloc((void**)&ctx->d_work, srt::TALLY_ALL * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc work counters");
     if ((e = hipMemsetAsync(ctx->d_fb_own, 0, px * sizeof(uint32_t), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
     if ((e = hipMemsetAsync(ctx->d_acc_own, 0, px * sizeof(float4), ctx->stream)) != hipSuccess) return bail(e, "hipMemset");
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
@@ -271,6 +285,7 @@ int srt_destroy(srt_context* ctx) {
     if (ctx->d_fb_own) (void)hipFree(ctx->d_fb_own);
     if (ctx->d_acc_own) (void)hipFree(ctx->d_acc_own);
     if (ctx->d_rays) (void)hipFree(ctx->d_rays);
+    if (ctx->d_work) (void)hipFree(ctx->d_work);
     if (ctx->d_bvh_nodes) (void)hipFree(ctx->d_bvh_nodes);
     if (ctx->d_bvh_tris) (void)hipFree(ctx->d_bvh_tris);
     if (ctx->d_bvh_gidpos) (void)hipFree(ctx->d_bvh_gidpos);
@@ -374,7 +389,7 @@ static int set_scene_impl(srt_context* ctx, const srt_object* objects, size_t co
     ctx->scene_set = true;
     ctx->order_stale = true;
     ctx->estimate_stale = true;
-    ctx->cost_sum = 0.0, ctx->cost_fill = 0.0;  // the recorded block costs describe another scene
+    ctx->work_sum = 0.0, ctx->work.clear();  // the recorded block work describes another scene
     // ... and so does a cost copy that may still be in flight, and the dispatch order made from the old scene's costs: both are
     // dropped (the stream was synchronised above, so nothing still writes h_wg_cost), the next launch estimates afresh
     ctx->recording = false;
@@ -458,8 +473,9 @@ int srt_set_stream(srt_context* ctx, void* hip_stream) {
 
 int srt_bind_output(srt_context* ctx, void* d_framebuffer, void* d_accumulator) {
     if (!ctx) return SRT_ERR_INVALID_ARG;
-    SRT_HIP(ctx, hipSetDevice(ctx->device));
-    SRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // (no synchronisation, round 4: a launch takes its buffer addresses when it is enqueued, so renders in flight keep writing
+    // the buffers they were given and only later calls see the new ones — which is what lets a caller render frame k + 1 into a
+    // second framebuffer while frame k is still being copied to the host, bench.py's overlapped read-back)
     ctx->d_fb = d_framebuffer ? (uint32_t*)d_framebuffer : ctx->d_fb_own;
     ctx->d_acc = d_accumulator ? (float4*)d_accumulator : ctx->d_acc_own;
     return SRT_OK;
@@ -548,6 +564,112 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
     return SRT_OK;
 }
 
+// What a block costs, from its counts: the weights are wave instructions per trip of the loop counted (a pool step costs its fixed
+// part plus the uniform-sphere groups, cluster bounds and boxes every step runs through), fitted on measured band times of
+// configs 3 and 5, Scene3, Scene_indirect and config 4's scene (tools/band_fit.py, profiles/r03/band_fit*.txt).  Valid for a probe
+// of PROBE_SAMPLES = 32 samples (shorter pools take more steps per sample) and, as relative weights, for a launch's own counts.
+struct ProbeWeights {
+    // a pool step: its fixed part + what every step runs through per group of four uniform spheres / cluster bound / box / mesh root test
+    double step = 700.0, step_ugroup = 70.0, step_cluster = 12.0, step_box = 45.0, step_mesh = 60.0;
+    double group = 760.0;          // four clustered spheres through the exact test for 64 items (carries the scatter, shuffles and merge of its round)
+    double node_round = 26.0, leaf_trip = 1300.0, mesh_phase = 65.0;  // BVH traversal (the leaf trips carry the memory round trips of the whole phase)
+    double wave = 5830.0;          // per tile: staging, primary rays, ring — what every sample chunk of a real launch repeats
+    double untraced_wave = 358.0;  // a tile with sample-independent pixels folds their colour sample by sample
+};
+static double probe_step_weight(const srt::KernelParams& K, const ProbeWeights& w) {
+    return w.step + w.step_ugroup * ((K.nu + 3) / 4) + w.step_cluster * K.nc + w.step_box * K.nb + (K.n_tris > 0 ? w.step_mesh : 0.0);
+}
+static double probe_block_cost(const uint32_t* c, const srt::KernelParams& K, const ProbeWeights& w) {
+    return probe_step_weight(K, w) * c[srt::TALLY_STEPS] + w.group * c[srt::TALLY_GROUPS] + w.node_round * c[srt::TALLY_NODE_ROUNDS] + w.leaf_trip * c[srt::TALLY_LEAF_TRIPS] +
+           w.mesh_phase * c[srt::TALLY_MESH_PHASES] + w.wave * c[srt::TALLY_WAVES] + w.untraced_wave * c[srt::TALLY_UNTRACED_WAVES];
+}
+
+// How full a launch of `layers` sample chunks keeps `slots` resident workgroups, from the recorded block works alone: the
+// workgroups are started layer by layer, dearest block first (the cost order of the real dispatch), each on the slot that frees
+// first, and run for work / layers; the result is sum of the run times / (slots x the time the last one ends).  A deterministic
+// stand-in for what round 3 read off the recorded launch's event time (wave time / launch time x resident waves): that figure
+// moved with the clock and flipped launch shapes near its threshold.
+static double simulate_fill(const std::vector<uint32_t>& sorted_work, int layers, int slots) {
+    if (sorted_work.empty() || slots < 1 || layers < 1) return 1.0;
+    std::vector<double> heap((size_t)slots, 0.0);  // min-heap of the slots' finish times
+    auto cmp = [](double a, double b) { return a > b; };
+    double sum = 0.0, end = 0.0;
+    for (int z = 0; z < layers; ++z)
+        for (uint32_t w : sorted_work) {
+            const double d = (double)w / (double)layers;
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            heap.back() += d;
+            end = heap.back() > end ? heap.back() : end;
+            std::push_heap(heap.begin(), heap.end(), cmp);
+            sum += d;
+        }
+    return end > 0.0 ? sum / (end * (double)slots) : 1.0;
+}
+
+// A recording launch's cost copy has completed: make the dispatch order of the following launches from the blocks' wave TIMES
+// (any order gives the same image) and the launch-shape record from the blocks' WORK (counts: the same in every run).
+static int consume_record(srt_context* ctx) {
+    ctx->recording = false;
+    const size_t n = (size_t)ctx->rec_gx * ctx->rec_gy;
+    if (ctx->order_gx) (void)hipEventSynchronize(ctx->ev_order);  // (long done) the previous upload read h_wg_order
+    // linear buckets between the cheapest and the dearest block, expensive first; the counting sort
+    // keeps the spatial order inside a bucket
+    const int NB = dev_switches().lpt_buckets;
+    // a launch whose blocks all cost about the same (5th..95th percentile within 1.5x) keeps the
+    // natural order: nothing to gain, and neighbouring blocks stay together
+    bool uniform = false;
+    {
+        std::vector<uint32_t> tmp(ctx->h_wg_cost, ctx->h_wg_cost + n);
+        std::nth_element(tmp.begin(), tmp.begin() + n / 20, tmp.end());
+        const double p05 = (double)tmp[n / 20];
+        std::nth_element(tmp.begin(), tmp.begin() + (n - 1 - n / 20), tmp.end());
+        const double p95 = (double)tmp[n - 1 - n / 20];
+        uniform = p95 <= 1.5 * p05;
+    }
+    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+    for (size_t i = 0; i < n; ++i) lo = ctx->h_wg_cost[i] < lo ? ctx->h_wg_cost[i] : lo, hi = ctx->h_wg_cost[i] > hi ? ctx->h_wg_cost[i] : hi;
+    // the launch-shape record: the second half of the copy (present when the recording launch kept its counts)
+    ctx->work_sum = 0.0, ctx->work_max = 0, ctx->work.clear();
+    if (ctx->rec_has_work) {
+        const uint32_t* wk = ctx->h_wg_cost + n;
+        ctx->work.assign(wk, wk + n);
+        std::sort(ctx->work.begin(), ctx->work.end(), [](uint32_t a, uint32_t b) { return a > b; });
+        for (uint32_t w : ctx->work) ctx->work_sum += (double)w;
+        ctx->work_max = ctx->work.empty() ? 0u : ctx->work.front();
+        ctx->cost_gx = ctx->rec_gx, ctx->cost_gy = ctx->rec_gy;
+    }
+#ifdef SRT_DEV
+    if (getenv("SRT_DEBUG_CHUNKS")) {  // the time-based figures of round 3 next to the counted ones, for calibration
+        double tsum = 0.0;
+        for (size_t i = 0; i < n; ++i) tsum += (double)ctx->h_wg_cost[i];
+        float ms = 0.0f;
+        double tfill = 0.0;
+        if (hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end) == hipSuccess && ms > 0.0f)
+            tfill = tsum * 1e-5 / ((double)ms * ctx->cu_count * (ctx->mesh_image.n_tris > 0 ? 16.0 : 20.0));
+        else
+            (void)hipGetLastError();
+        const double slots = (double)ctx->cu_count * (ctx->mesh_image.n_tris > 0 ? 3.0 : 4.0);
+        fprintf(stderr, "record: %zu blocks grid %u x %u | TIME dearest %u sum %.0f ratio %.3f fill %.3f (%.3f ms) | WORK dearest %u sum %.0f ratio %.3f", n, ctx->rec_gx, ctx->rec_gy,
+                hi, tsum, tsum > 0 ? hi * slots / tsum : 0.0, tfill, ms, ctx->work_max, ctx->work_sum, ctx->work_sum > 0 ? ctx->work_max * slots / ctx->work_sum : 0.0);
+        const int wslots = ctx->cu_count * (ctx->mesh_image.n_tris > 0 ? 4 : 5);
+        for (int c : {1, 2, 3, 4, 6, 8}) fprintf(stderr, " fill(%d)=%.3f", c, simulate_fill(ctx->work, c, wslots));
+        fprintf(stderr, "\n");
+    }
+#endif
+    const double scale = hi > lo ? (double)(NB - 1) / (double)(hi - lo) : 0.0;
+    auto bucket = [&](uint32_t c) { return (NB - 1) - (int)((double)(c - lo) * scale); };
+    std::vector<size_t> start((size_t)NB + 1, 0);
+    for (size_t i = 0; i < n; ++i) ++start[(size_t)bucket(ctx->h_wg_cost[i]) + 1];
+    for (int k = 0; k < NB; ++k) start[(size_t)k + 1] += start[(size_t)k];
+    for (size_t i = 0; i < n; ++i) ctx->h_wg_order[start[(size_t)bucket(ctx->h_wg_cost[i])]++] = (uint32_t)i;
+    if (uniform)
+        for (size_t i = 0; i < n; ++i) ctx->h_wg_order[i] = (uint32_t)i;
+    SRT_HIP(ctx, hipMemcpyAsync(ctx->d_wg_order, ctx->h_wg_order, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    SRT_HIP(ctx, hipEventRecord(ctx->ev_order, ctx->stream));
+    ctx->order_gx = ctx->rec_gx, ctx->order_gy = ctx->rec_gy;
+    return SRT_OK;
+}
+
 extern "C" {
 
 int srt_render(srt_context* ctx, const srt_render_params* p) {
@@ -571,19 +693,30 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     size_t lds_bytes = 0;
     int use = 0;
     int img = 0;
-    fill_kernel_params(ctx, p, K, lds_bytes, use, img);
+    const int fill_rc = fill_kernel_params(ctx, p, K, lds_bytes, use, img);
+    if (fill_rc != SRT_OK) return fill_rc;
     ctx->count_rays = (p->flags & SRT_RENDER_COUNT_RAYS) != 0;
     if (ctx->count_rays) SRT_HIP(ctx, hipMemsetAsync(ctx->d_rays, 0, sizeof(unsigned long long), ctx->stream));
-    // The learned dispatch order, a cost copy in flight and the cost figures of the chunk rule describe ONE row band.  Another
+    // The learned dispatch order, a cost copy in flight and the work record of the chunk rule describe ONE row band.  Another
     // band of the same height has the same grid but other blocks behind every index: it starts from a fresh estimate, like a new
     // scene.  (Found the hard way: a 270-row band of config 5 launched after its neighbour inherited "no sample chunks" and
     // ran 46 ms instead of 12.)
     if (K.y0 != ctx->band_y0 || K.rows != ctx->band_rows) {
+        if (ctx->recording) (void)hipEventSynchronize(ctx->ev_cost);  // (nothing may still write h_wg_cost when the next record starts)
         ctx->band_y0 = K.y0, ctx->band_rows = K.rows;
         ctx->order_stale = ctx->estimate_stale = true;
-        ctx->cost_sum = 0.0, ctx->cost_fill = 0.0;
+        ctx->work_sum = 0.0, ctx->work.clear();
         ctx->recording = false;
         ctx->order_gx = ctx->order_gy = 0;
+    }
+    // A record in flight is WAITED for (round 3 polled it): the launch after a recording launch always sees the record, whatever the
+    // host's timing — so which launch of a sequence changes to the recorded shape and order does not vary from run to run.  The
+    // wait ends when the recording launch does; it happens once per scene / camera / band change (a launch records only then),
+    // and costs the one enqueue that could have overlapped that launch's tail.
+    if (ctx->recording) {
+        SRT_HIP(ctx, hipEventSynchronize(ctx->ev_cost));
+        const int rc = consume_record(ctx);
+        if (rc != SRT_OK) return rc;
     }
 
     // Tile height: with few rows and many samples per pixel (a narrow stripe of a multi-GPU frame) 8-row
@@ -619,15 +752,19 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     // few long ones whose tail idles the chip: 135 rows x 256 spp 4.9 ms -> 2.2 ms, and still ~10 % on a
     // full 1080p frame at 256 spp.  Costs 1 KiB of HBM per tile and sample (falls back to small tiles
     // when that is not available).
+    // Everything this rule reads is a count: the request, the grid, the chip's CU count and — once the band's recording launch has
+    // run — the blocks' recorded WORK (loop trips, not times).  Same inputs and call history, same shape (round 4; round 3 read the
+    // blocks' wave times and the launch's event time, and config 5's rank-4 band flipped between one piece and nine layers).
     const int defer_env = dev_switches().defer;  // 0: never, n > 0: force n samples per chunk
     const long long wg_y8 = (K.rows + srt::WG_H - 1) / srt::WG_H, wg8 = wg_x * wg_y8;
     int chunk = 0, chunks = 1;
+    uint32_t shape_source = 0;  // 0: the static rule (request and grid only), 1: the band's work record
     // (scenes with meshes from 32 spp: their few, heavy tiles profit earlier — config 4 at 32 spp +20 %)
     // (progressive blocks, steps > 1, are traced once per block by the multi-sample instantiation: no sample chunks)
     if (tile_env == 0 && defer_env != 0 && (p->sample_count >= 64 || defer_env > 0 || K.n_tris > 0) && p->sample_count >= 32 && K.steps <= 1) {
         long long c = (96LL * ctx->cu_count + wg8 - 1) / wg8;  // about 24 k workgroups in flight over the launch
-        // With block costs recorded for this grid (an earlier launch of the frame) the number of chunks follows from how
-        // uneven the blocks are: ratio = the dearest block (99.5th percentile) over an even share of the whole launch per
+        // With block works recorded for this grid (the band's recording launch) the number of chunks follows from how
+        // uneven the blocks are: ratio = the dearest block over an even share of the whole launch per
         // resident workgroup.  Well below 1 the cost order alone fills the chip — no chunks for meshes (every chunk repeats
         // the primary hits, mesh phases included, and the colours make a round trip through the sample buffer: config 4,
         // ratio 0.56, 10.4 -> 9.3 ms; config 5's rank-4 band, 0.80, 74 -> 69-72 ms), two for analytic scenes (finer grains
@@ -637,12 +774,14 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
         // (no record yet: a mesh launch of >= 6000 blocks — a whole 1080p frame — starts unchunked, which is what the record
         // of such a frame asks for; smaller ones, the bands of a multi-GPU frame, start with the workgroup-count rule above)
         if (K.n_tris > 0 && wg8 >= 6000) c = 1;
-        if (ctx->cost_sum > 0.0 && ctx->cost_gx == (unsigned)wg_x && ctx->cost_gy == (unsigned)wg_y8) {
+        const bool have_record = ctx->work_sum > 0.0 && ctx->cost_gx == (unsigned)wg_x && ctx->cost_gy == (unsigned)wg_y8;
+        if (have_record) {
             const double slots = (double)ctx->cu_count * (K.n_tris > 0 ? 3.0 : 4.0);
-            const double ratio = (double)ctx->cost_max * slots / ctx->cost_sum;
+            const double ratio = (double)ctx->work_max * slots / ctx->work_sum;
             c = ratio < 0.85 ? (K.n_tris > 0 ? 1 : 2) : (long long)ceil(ratio * 100.0 / (double)dev_switches().chunk_beta);
+            shape_source = 1;
 #ifdef SRT_DEV
-            if (getenv("SRT_DEBUG_CHUNKS")) fprintf(stderr, "chunks: dearest %u sum %.0f blocks %lld slots %.0f ratio %.3f fill %.3f -> c %lld\n", ctx->cost_max, ctx->cost_sum, wg8, slots, ratio, ctx->cost_fill, c);
+            if (getenv("SRT_DEBUG_CHUNKS")) fprintf(stderr, "chunks: dearest %u sum %.0f blocks %lld slots %.0f ratio %.3f -> c %lld\n", ctx->work_max, ctx->work_sum, wg8, slots, ratio, c);
 #endif
         }
         // Analytic scenes, round 3 (five resident workgroups per CU, ring of two): at least ten rounds of workgroups, whatever the
@@ -661,13 +800,20 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             // 1.9 rounds: config 5's floor band 1812-1938 76.9 ms, 74.6 with two chunks, 72.9 with eight.
             const long long c_fill = (4LL * 4 * ctx->cu_count + wg8 / 2) / wg8;  // (to the nearest: 4080 blocks are four rounds)
             if (c < c_fill) c = c_fill;
-            // ... and a launch that left a quarter of the chip's wave slots empty is cut into four: the upper 1066 rows of config 5
-            // (sky, far spheres, mirror balls: half of its blocks cost nothing, the dear ones make 4.5 rounds) filled 0.73 of the
-            // slots in one piece, 76.8 ms; 66.5 with three chunks, 64.4 with six.  Its neighbours fill 0.94..0.96 and lose 1..5 %
-            // to any chunking — no figure of the cost record itself tells them apart, the launch's own time does.
+            // ... and a launch that would leave a good part of the chip's workgroup slots empty is cut into four: the upper 1066 rows
+            // of config 5 (sky, far spheres, mirror balls: half of its blocks cost nothing, the dear ones make 4.5 rounds) filled 0.73
+            // of the slots in one piece, 76.8 ms; 66.5 with three chunks, 64.4 with six.  Its neighbours fill 0.94..0.96 and lose 1..5 %
+            // to any chunking.  Round 3 took the fill from the recorded launch's event time; now it is simulate_fill() over the recorded
+            // works: list scheduling of the launch as planned so far.
             // (Only where a chunk still has 64 samples and more: config 4's frame, 64 spp, fills 0.8 of the slots in its first launch
             // too, and in four chunks of 16 samples it ran 8.05 ms instead of 7.17.)
-            if (ctx->cost_fill > 0.0 && ctx->cost_fill < 0.85 && c < 4 && p->sample_count >= 256 && ctx->cost_gx == (unsigned)wg_x && ctx->cost_gy == (unsigned)wg_y8) c = 4;
+            if (have_record && c < 4 && p->sample_count >= 256) {
+                const double fill = simulate_fill(ctx->work, (int)c, ctx->cu_count * 4);
+#ifdef SRT_DEV
+                if (getenv("SRT_DEBUG_CHUNKS")) fprintf(stderr, "chunks: simulated fill of %lld layer(s) %.3f (threshold %.2f)\n", c, fill, SRT_FILL_MIN);
+#endif
+                if (fill < SRT_FILL_MIN) c = 4;
+            }
         }
         if (c > p->sample_count / min_chunk) c = p->sample_count / min_chunk;
         // A mesh launch that the rule leaves in ONE piece keeps full 8 x 8 tiles: the small tiles chosen above for launches of few
@@ -731,11 +877,12 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     // last ones to start are whatever lies at the top of the band, and the chip idles while a few expensive
     // blocks finish.  Starting blocks in order of decreasing cost (coarse buckets, so that neighbours stay
     // together) removes most of that tail: Scene1 3.39 -> 3.25 ms, config 4 19.7 -> 17.5 ms.  Costs are
-    // the blocks' wave-cycles in an earlier launch of the same grid, copied back asynchronously and only
-    // polled — a launch never waits for them, and any order gives the same image.
+    // the blocks' wave-cycles in the band's recording launch (the first after a scene, camera or band change), copied back
+    // asynchronously; the next srt_render of the handle waits for that copy (see above).  Any order gives the same image.
     const bool order_env = dev_switches().lpt;
     bool record = false;
     const size_t nwg = (size_t)grid.x * grid.y;
+    const bool in_lds = ctx->scene_in_lds[img];
     if (order_env && !ctx->order_disabled && nwg >= SRT_ORDER_MIN_WG && p->sample_count >= 4 && !(p->flags & SRT_RENDER_PREVIEW) && !bgrid) {
         if (nwg > ctx->wg_capacity) {
             SRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -750,9 +897,10 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             ctx->recording = false;
             // an optimisation must not be able to fail a render: if anything here cannot be had (pinned host
             // memory, for one), the handle simply keeps the natural order from now on
-            const bool ok = hipMalloc((void**)&ctx->d_wg_cost, nwg * 4) == hipSuccess && hipMalloc((void**)&ctx->d_wg_order, nwg * 4) == hipSuccess &&
+            // (cost buffers: the blocks' wave times, then the blocks' work)
+            const bool ok = hipMalloc((void**)&ctx->d_wg_cost, 2 * nwg * 4) == hipSuccess && hipMalloc((void**)&ctx->d_wg_order, nwg * 4) == hipSuccess &&
                             hipMalloc((void**)&ctx->d_wg_est, 2 * nwg * 4) == hipSuccess &&  // raw + smoothed
-                            hipHostMalloc((void**)&ctx->h_wg_cost, nwg * 4, hipHostMallocDefault) == hipSuccess &&
+                            hipHostMalloc((void**)&ctx->h_wg_cost, 2 * nwg * 4, hipHostMallocDefault) == hipSuccess &&
                             hipHostMalloc((void**)&ctx->h_wg_order, nwg * 4, hipHostMallocDefault) == hipSuccess &&
                             (ctx->ev_cost || hipEventCreateWithFlags(&ctx->ev_cost, hipEventDisableTiming) == hipSuccess) &&
                             (ctx->ev_order || hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming) == hipSuccess);
@@ -765,73 +913,11 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
         }
     }
     if (order_env && !ctx->order_disabled && ctx->wg_capacity >= nwg && nwg >= SRT_ORDER_MIN_WG && p->sample_count >= 4 && !(p->flags & SRT_RENDER_PREVIEW) && !bgrid) {
-        const hipError_t arrived = ctx->recording ? hipEventQuery(ctx->ev_cost) : hipErrorNotReady;
-        if (arrived != hipSuccess) (void)hipGetLastError();  // "not ready" must not surface as this launch's error
-        if (arrived == hipSuccess) {  // costs have arrived: make the order
-            ctx->recording = false;
-            const size_t n = (size_t)ctx->rec_gx * ctx->rec_gy;
-            if (ctx->order_gx) (void)hipEventSynchronize(ctx->ev_order);  // (long done) the previous upload read h_wg_order
-            // linear buckets between the cheapest and the dearest block, expensive first; the counting sort
-            // keeps the spatial order inside a bucket
-            const int NB = dev_switches().lpt_buckets;
-            // a launch whose blocks all cost about the same (5th..95th percentile within 1.5x) keeps the
-            // natural order: nothing to gain, and neighbouring blocks stay together
-            bool uniform = false;
-            {
-                std::vector<uint32_t> tmp(ctx->h_wg_cost, ctx->h_wg_cost + n);
-                std::nth_element(tmp.begin(), tmp.begin() + n / 20, tmp.end());
-                const double p05 = (double)tmp[n / 20];
-                std::nth_element(tmp.begin(), tmp.begin() + (n - 1 - n / 20), tmp.end());
-                const double p95 = (double)tmp[n - 1 - n / 20];
-                uniform = p95 <= 1.5 * p05;
-            }
-            uint32_t lo = 0xFFFFFFFFu, hi = 0;
-            double sum = 0.0;
-            for (size_t i = 0; i < n; ++i) lo = ctx->h_wg_cost[i] < lo ? ctx->h_wg_cost[i] : lo, hi = ctx->h_wg_cost[i] > hi ? ctx->h_wg_cost[i] : hi, sum += (double)ctx->h_wg_cost[i];
-#ifdef SRT_DEV
-            if (getenv("SRT_DEBUG_CHUNKS")) {
-                size_t bad = 0;
-                for (size_t i = 0; i < n; ++i)
-                    if (ctx->h_wg_cost[i] > 0x40000000u) {
-                        if (bad < 6) fprintf(stderr, "cost[%zu] (bx %zu by %zu) = %u (as int %d)\n", i, i % ctx->rec_gx, i / ctx->rec_gx, ctx->h_wg_cost[i], (int)ctx->h_wg_cost[i]);
-                        ++bad;
-                    }
-                fprintf(stderr, "costs arrived: %zu blocks, %zu suspicious, grid %u x %u\n", n, bad, ctx->rec_gx, ctx->rec_gy);
-            }
-#endif
-            // What the sample-chunk rule looks at: the dearest block — the maximum itself (a 99.5th percentile until round 3, from the
-            // days of the block-cost timer's stray records, §4.3; a record that is too high costs a few chunks too many, a dear block
-            // that is overlooked costs the tail).
-            ctx->cost_sum = sum, ctx->cost_max = hi, ctx->cost_gx = ctx->rec_gx, ctx->cost_gy = ctx->rec_gy;
-            {   // how full the chip was during the recorded launch: the waves' run time (10 ns ticks) against the launch's own time
-                // (its events completed before the cost copy did) x the waves a chip holds of this kernel
-                float ms = 0.0f;
-                ctx->cost_fill = 0.0;
-                if (hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end) == hipSuccess && ms > 0.0f)
-                    ctx->cost_fill = sum * 1e-5 / ((double)ms * ctx->cu_count * (ctx->mesh_image.n_tris > 0 ? 16.0 : 20.0));
-                else
-                    (void)hipGetLastError();
-#ifdef SRT_DEV
-                if (getenv("SRT_DEBUG_CHUNKS")) fprintf(stderr, "recorded launch: %.3f ms, wave time %.1f wave-ms, dearest block %u ticks, fill %.3f\n", ms, sum * 1e-5, hi, ctx->cost_fill);
-#endif
-            }
-            const double scale = hi > lo ? (double)(NB - 1) / (double)(hi - lo) : 0.0;
-            auto bucket = [&](uint32_t c) { return (NB - 1) - (int)((double)(c - lo) * scale); };
-            std::vector<size_t> start((size_t)NB + 1, 0);
-            for (size_t i = 0; i < n; ++i) ++start[(size_t)bucket(ctx->h_wg_cost[i]) + 1];
-            for (int k = 0; k < NB; ++k) start[(size_t)k + 1] += start[(size_t)k];
-            for (size_t i = 0; i < n; ++i) ctx->h_wg_order[start[(size_t)bucket(ctx->h_wg_cost[i])]++] = (uint32_t)i;
-            if (uniform)
-                for (size_t i = 0; i < n; ++i) ctx->h_wg_order[i] = (uint32_t)i;
-            SRT_HIP(ctx, hipMemcpyAsync(ctx->d_wg_order, ctx->h_wg_order, n * 4, hipMemcpyHostToDevice, ctx->stream));
-            SRT_HIP(ctx, hipEventRecord(ctx->ev_order, ctx->stream));
-            ctx->order_gx = ctx->rec_gx, ctx->order_gy = ctx->rec_gy;
-        }
-        // No recorded costs for this frame yet (first launch, or the scene / camera has changed): estimate the blocks'
+        // No recorded costs for this frame yet (first launch, or the scene has changed): estimate the blocks'
         // costs on the device — 16 one-sample probe paths per block, block_cost_kernel — and sort them there (order_sort_kernel);
         // both run on the launch stream ahead of the frame, nothing comes back to the host.  Measured with warm clocks:
         // first launch of a frame vs the learned order: config 4 +13 % -> see DESIGN.md, Scene1 +3 %.
-        if (dev_switches().host_order && arrived != hipSuccess && (ctx->estimate_stale || ctx->order_gx != grid.x || ctx->order_gy != grid.y)) {
+        if (dev_switches().host_order && (ctx->estimate_stale || ctx->order_gx != grid.x || ctx->order_gy != grid.y)) {
             const size_t image_bytes = (size_t)(K.scene_vec4 > 0 ? K.scene_vec4 : 1) * sizeof(float4);
             const size_t est_lds = (ctx->pick_in_lds[img] ? image_bytes : 0) + srt::WAVE_SCRATCH_BYTES + srt::MESH_WAVE_BYTES;
             if (ctx->pick_in_lds[img])
@@ -848,19 +934,39 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             }
         }
         if (ctx->order_gx == grid.x && ctx->order_gy == grid.y) K.wg_order = ctx->d_wg_order;
-        if (!ctx->recording && (ctx->order_stale || ctx->order_gx != grid.x || ctx->order_gy != grid.y)) {
-            SRT_HIP(ctx, hipMemsetAsync(ctx->d_wg_cost, 0, nwg * 4, ctx->stream));
+        if (ctx->order_stale || ctx->order_gx != grid.x || ctx->order_gy != grid.y) {  // (no record is in flight here: it was waited for above)
+            SRT_HIP(ctx, hipMemsetAsync(ctx->d_wg_cost, 0, 2 * nwg * 4, ctx->stream));
             K.wg_cost = ctx->d_wg_cost;
+            K.wg_blocks = (uint32_t)nwg;
             record = true;
+        }
+    }
+    // The TALLY instantiations keep the wave-uniform loop counts (srt_kernel.hip.h, Tally): the recording launch of a band (its
+    // blocks' work is the launch-shape record) and launches with SRT_RENDER_COUNT_WORK.  Scene images that live in HBM have none
+    // (a correctness fallback): such launches keep the static shape rule and report no work counts.
+    const bool want_work = (p->flags & SRT_RENDER_COUNT_WORK) != 0;
+    const bool tally = (record || want_work) && in_lds;
+    ctx->count_work = want_work;
+    ctx->count_work_valid = want_work && tally;
+    if (tally) {
+        const ProbeWeights pw;
+        const double wv[7] = {probe_step_weight(K, pw), pw.group, pw.node_round, pw.leaf_trip, pw.mesh_phase, pw.wave, pw.untraced_wave};
+        for (int i = 0; i < 7; ++i) K.work_w[i] = (uint32_t)(wv[i] + 0.5);
+        if (want_work) {
+            SRT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, srt::TALLY_ALL * sizeof(unsigned long long), ctx->stream));
+            K.work_counter = ctx->d_work;
         }
     }
     SRT_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     // instantiation: mesh or not, scene image in LDS or HBM, full tiles / small tiles (multi-sample
-    // hand-out) / sample chunks; variants 1 / 3 are a development aid for in-process A/B timing.
-    // All are bit-identical.
-    const bool in_lds = ctx->scene_in_lds[img], multi = tile_h < srt::TILE_H || (K.steps > 1 && !(K.flags & SRT_RENDER_PREVIEW)) || bgrid;
-    auto launch = [&](auto k_lds, auto k_lds_multi, auto k_lds_defer, auto k_hbm, auto k_hbm_multi, auto k_hbm_defer) {
-        if (in_lds && defer) hipLaunchKernelGGL(k_lds_defer, grid, block, lds_bytes, ctx->stream, K);
+    // hand-out) / sample chunks, with or without the loop counts; variants 1 / 3 are a development aid for in-process A/B
+    // timing.  All are bit-identical.
+    const bool multi = tile_h < srt::TILE_H || (K.steps > 1 && !(K.flags & SRT_RENDER_PREVIEW)) || bgrid;
+    auto launch = [&](auto k_lds, auto k_lds_multi, auto k_lds_defer, auto k_hbm, auto k_hbm_multi, auto k_hbm_defer, auto t_lds, auto t_lds_multi, auto t_lds_defer) {
+        if (tally && defer) hipLaunchKernelGGL(t_lds_defer, grid, block, lds_bytes, ctx->stream, K);
+        else if (tally && multi) hipLaunchKernelGGL(t_lds_multi, grid, block, lds_bytes, ctx->stream, K);
+        else if (tally) hipLaunchKernelGGL(t_lds, grid, block, lds_bytes, ctx->stream, K);
+        else if (in_lds && defer) hipLaunchKernelGGL(k_lds_defer, grid, block, lds_bytes, ctx->stream, K);
         else if (in_lds && multi) hipLaunchKernelGGL(k_lds_multi, grid, block, lds_bytes, ctx->stream, K);
         else if (in_lds) hipLaunchKernelGGL(k_lds, grid, block, lds_bytes, ctx->stream, K);
         else if (defer) hipLaunchKernelGGL(k_hbm_defer, grid, block, lds_bytes, ctx->stream, K);
@@ -870,11 +976,13 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     if (K.n_tris > 0)  // EXTENSION: scenes with triangle meshes use the BVH-enabled instantiation
         launch(srt::pathtrace_kernel<4, true, true, false, false>, srt::pathtrace_kernel<4, true, true, true, false>,
                srt::pathtrace_kernel<4, true, true, false, true>, srt::pathtrace_kernel<4, true, false, false, false>,
-               srt::pathtrace_kernel<4, true, false, true, false>, srt::pathtrace_kernel<4, true, false, false, true>);
+               srt::pathtrace_kernel<4, true, false, true, false>, srt::pathtrace_kernel<4, true, false, false, true>,
+               srt::pathtrace_kernel<4, true, true, false, false, false, true>, srt::pathtrace_kernel<4, true, true, true, false, false, true>,
+               srt::pathtrace_kernel<4, true, true, false, true, false, true>);
 #ifdef SRT_DEV  // occupancy variants for A/B timing; never in the shipped library
-    else if (use == 1 && in_lds && !multi && !defer)
+    else if (use == 1 && in_lds && !multi && !defer && !tally)
         hipLaunchKernelGGL((srt::pathtrace_kernel<4, false>), grid, block, lds_bytes, ctx->stream, K);
-    else if (use == 3 && in_lds && !multi && !defer)
+    else if (use == 3 && in_lds && !multi && !defer && !tally)
         hipLaunchKernelGGL((srt::pathtrace_kernel<3, false>), grid, block, lds_bytes, ctx->stream, K);
 #endif
     else
@@ -883,7 +991,9 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
         // progressive blocks included (it stayed at four waves before: 111), and the mesh kernels 119..125: four waves, no spill)
         launch(srt::pathtrace_kernel<5, false, true, false, false>, srt::pathtrace_kernel<5, false, true, true, false>,
                srt::pathtrace_kernel<5, false, true, false, true>, srt::pathtrace_kernel<5, false, false, false, false>,
-               srt::pathtrace_kernel<5, false, false, true, false>, srt::pathtrace_kernel<5, false, false, false, true>);
+               srt::pathtrace_kernel<5, false, false, true, false>, srt::pathtrace_kernel<5, false, false, false, true>,
+               srt::pathtrace_kernel<5, false, true, false, false, false, true>, srt::pathtrace_kernel<5, false, true, true, false, false, true>,
+               srt::pathtrace_kernel<5, false, true, false, true, false, true>);
     if (defer) {
         SRT_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(srt::fold_kernel, dim3((unsigned)wg8), dim3(256), 0, ctx->stream, K, (int)wg_x);
@@ -891,16 +1001,21 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     SRT_HIP(ctx, hipGetLastError());
     SRT_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
     if (record) {
-        SRT_HIP(ctx, hipMemcpyAsync(ctx->h_wg_cost, ctx->d_wg_cost, nwg * 4, hipMemcpyDeviceToHost, ctx->stream));
+        SRT_HIP(ctx, hipMemcpyAsync(ctx->h_wg_cost, ctx->d_wg_cost, 2 * nwg * 4, hipMemcpyDeviceToHost, ctx->stream));
         SRT_HIP(ctx, hipEventRecord(ctx->ev_cost, ctx->stream));
         ctx->recording = true;
         ctx->rec_gx = grid.x, ctx->rec_gy = grid.y;
+        ctx->rec_has_work = tally;
         ctx->order_stale = false;
     }
     ctx->launched = true;
     ctx->stats_pending = true;
     ctx->pending_samples = (uint64_t)W * (uint64_t)K.rows * p->sample_count;
     ctx->pending_chunks = (uint32_t)chunks;
+    ctx->pending_tile_rows = (uint32_t)tile_h;
+    ctx->pending_chunk_samples = defer ? (uint32_t)chunk : 0u;
+    ctx->pending_shape_source = shape_source;
+    ctx->work_layout[0] = K.nu, ctx->work_layout[1] = K.nc, ctx->work_layout[2] = K.K, ctx->work_layout[3] = K.nb;
     return SRT_OK;
 }
 
@@ -952,7 +1067,7 @@ int srt_pick(srt_context* ctx, int x, int y, int* object_index) {
     size_t lds_bytes = 0;
     int use = 0;
     int img = 0;
-    fill_kernel_params(ctx, &p, K, lds_bytes, use, img);
+    if (const int frc = fill_kernel_params(ctx, &p, K, lds_bytes, use, img)) return frc;
     int* d_out = ctx->d_pick;
     // one wave: image (if it fits) + one wave's scratch + one wave's mesh queues
     const size_t image_bytes = (size_t)(K.scene_vec4 > 0 ? K.scene_vec4 : 1) * sizeof(float4);
@@ -1003,7 +1118,31 @@ int srt_get_stats(srt_context* ctx, srt_stats* out) {
         ctx->stats.kernel_ms = ms;
         ctx->stats.path_samples = ctx->pending_samples;
         ctx->stats.sample_chunks = ctx->pending_chunks;
+        ctx->stats.tile_rows = ctx->pending_tile_rows;
+        ctx->stats.chunk_samples = ctx->pending_chunk_samples;
+        ctx->stats.shape_source = ctx->pending_shape_source;
         ctx->stats.rays = 0;
+        memset(&ctx->work_counts, 0, sizeof ctx->work_counts);
+        if (ctx->count_work && ctx->count_work_valid) {
+            unsigned long long t[srt::TALLY_ALL];
+            SRT_HIP(ctx, hipMemcpy(t, ctx->d_work, sizeof t, hipMemcpyDeviceToHost));
+            srt_work_counts& wc = ctx->work_counts;
+            const uint64_t nu = (uint64_t)ctx->work_layout[0], nc = (uint64_t)ctx->work_layout[1], nb = (uint64_t)ctx->work_layout[3];
+            wc.valid = 1;
+            wc.waves = t[srt::TALLY_WAVES];
+            wc.pool_steps = t[srt::TALLY_STEPS];
+            wc.closest_hit_calls = t[srt::TALLY_CALLS];
+            // a wave runs every trip of these loops for all of its 64 lanes, whatever they carry: executed tests = trips x 64
+            wc.uniform_sphere_tests = t[srt::TALLY_CALLS] * nu * 64u;
+            wc.box_tests = t[srt::TALLY_CALLS] * nb * 64u;
+            wc.cluster_bound_tests = t[srt::TALLY_BOUND_CALLS] * nc * 64u;
+            wc.cluster_sphere_tests = t[srt::TALLY_GROUPS] * 4u * 64u;
+            wc.cluster_items = t[srt::TALLY_ITEMS];
+            wc.bvh_child_tests = t[srt::TALLY_NODE_TESTS] * 64u;
+            wc.triangle_tests = t[srt::TALLY_LEAF_TRIPS] * 64u;
+            wc.bvh_node_rounds = t[srt::TALLY_NODE_ROUNDS];
+            wc.mesh_phases = t[srt::TALLY_MESH_PHASES];
+        }
         if (ctx->count_rays) {
             unsigned long long r = 0;
             SRT_HIP(ctx, hipMemcpy(&r, ctx->d_rays, sizeof r, hipMemcpyDeviceToHost));
@@ -1012,6 +1151,16 @@ int srt_get_stats(srt_context* ctx, srt_stats* out) {
         ctx->stats_pending = false;
     }
     *out = ctx->stats;
+    return SRT_OK;
+}
+
+int srt_get_work_counts(srt_context* ctx, srt_work_counts* out) {
+    if (!ctx || !out) return SRT_ERR_INVALID_ARG;
+    srt_stats st;
+    const int rc = srt_get_stats(ctx, &st);  // waits, and reads the counters of the last render back
+    if (rc != SRT_OK) return rc;
+    if (!ctx->count_work) return fail(ctx, SRT_ERR_STATE, "srt_get_work_counts: the last srt_render did not ask for SRT_RENDER_COUNT_WORK");
+    *out = ctx->work_counts;
     return SRT_OK;
 }
 
@@ -1050,7 +1199,7 @@ static int run_pool_probe(srt_context* ctx, int max_bounces, uint32_t seed, std:
     srt::KernelParams K;
     size_t lds_bytes = 0;
     int use = 0, img = 0;
-    fill_kernel_params(ctx, &p, K, lds_bytes, use, img);
+    if (const int frc = fill_kernel_params(ctx, &p, K, lds_bytes, use, img)) return frc;
     K.flags = (K.flags & srt::KF_BOXES_FINITE) | SRT_RENDER_RESET;
     K.tile_h = srt::TILE_H;
     K.accumulator = nullptr, K.framebuffer = nullptr, K.ray_counter = nullptr;  // the probe touches none of them
@@ -1077,23 +1226,6 @@ static int run_pool_probe(srt_context* ctx, int max_bounces, uint32_t seed, std:
     return SRT_OK;
 }
 
-// What a block costs, from its counts: the weights are wave instructions per trip of the loop counted (a pool step costs its fixed
-// part plus the uniform-sphere groups, cluster bounds and boxes every step runs through), fitted on measured band times of
-// configs 3 and 5, Scene3, Scene_indirect and config 4's scene (tools/band_fit.py, profiles/r03/band_fit*.txt).
-struct ProbeWeights {
-    // a pool step: its fixed part + what every step runs through per group of four uniform spheres / cluster bound / box / mesh root test
-    double step = 700.0, step_ugroup = 70.0, step_cluster = 12.0, step_box = 45.0, step_mesh = 60.0;
-    double group = 760.0;          // four clustered spheres through the exact test for 64 items (carries the scatter, shuffles and merge of its round)
-    double node_round = 26.0, leaf_trip = 1300.0, mesh_phase = 65.0;  // BVH traversal (the leaf trips carry the memory round trips of the whole phase)
-    double wave = 5830.0;          // per tile: staging, primary rays, ring — what every sample chunk of a real launch repeats
-    double untraced_wave = 358.0;  // a tile with sample-independent pixels folds their colour sample by sample
-};
-static double probe_block_cost(const uint32_t* c, const srt::KernelParams& K, const ProbeWeights& w) {
-    const double step = w.step + w.step_ugroup * ((K.nu + 3) / 4) + w.step_cluster * K.nc + w.step_box * K.nb + (K.n_tris > 0 ? w.step_mesh : 0.0);
-    return step * c[srt::TALLY_STEPS] + w.group * c[srt::TALLY_GROUPS] + w.node_round * c[srt::TALLY_NODE_ROUNDS] + w.leaf_trip * c[srt::TALLY_LEAF_TRIPS] +
-           w.mesh_phase * c[srt::TALLY_MESH_PHASES] + w.wave * c[srt::TALLY_WAVES] + w.untraced_wave * c[srt::TALLY_UNTRACED_WAVES];
-}
-
 int srt_estimate_row_costs(srt_context* ctx, int max_bounces, uint32_t seed, float* row_costs) {
     if (!ctx || !row_costs) return SRT_ERR_INVALID_ARG;
     if (!ctx->scene_set) return fail(ctx, SRT_ERR_STATE, "srt_estimate_row_costs: srt_set_scene has not been called");
@@ -1109,7 +1241,7 @@ int srt_estimate_row_costs(srt_context* ctx, int max_bounces, uint32_t seed, flo
     srt::KernelParams K;
     size_t lds_bytes = 0;
     int use = 0, img = 0;
-    fill_kernel_params(ctx, &p, K, lds_bytes, use, img);
+    if (const int frc = fill_kernel_params(ctx, &p, K, lds_bytes, use, img)) return frc;
     const ProbeWeights w;
     // a block covers WG_H scene rows; its cost is spread evenly over them; memory row m = scene row H - 1 - m
     for (int m = 0; m < H; ++m) row_costs[m] = 0.0f;
@@ -1174,17 +1306,29 @@ int srt_gather_band(srt_context* dst, srt_context* src, int row_begin, int row_e
     hipError_t e = hipSetDevice(src->device);
     const char* what = "hipSetDevice";
     if (e == hipSuccess && src->device != dst->device) {
-        // direct xGMI path where the topology offers it (enabled once per pair of devices and source context); without peer
-        // access the runtime stages the copy.  NOTE: this branch needs two GPUs and has never executed on this project's
-        // one-GPU boxes — it is unverified code.
-        if (dst->device < 64 && !((src->peer_enabled >> dst->device) & 1ull)) {
-            const hipError_t pe = hipDeviceEnablePeerAccess(dst->device, 0);
-            if (pe != hipSuccess) (void)hipGetLastError();  // already enabled, or not available: both fine
-            src->peer_enabled |= 1ull << dst->device;
+        // direct xGMI path where the topology offers it: asked once per pair of devices and source context
+        // (hipDeviceCanAccessPeer), enabled once; without peer access the runtime stages the copy through the host.
+        // NOTE: this branch needs two GPUs and has never executed on this project's one-GPU boxes — it is
+        // unverified code; srt_gather_path() says which way a gather went, so the first multi-GPU run tells.
+        const unsigned long long bit = dst->device < 64 ? 1ull << dst->device : 0ull;
+        if (bit && !(src->peer_asked & bit)) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, src->device, dst->device) != hipSuccess) can = 0, (void)hipGetLastError();
+            if (can) {
+                const hipError_t pe = hipDeviceEnablePeerAccess(dst->device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) can = 0;
+                if (pe != hipSuccess) (void)hipGetLastError();
+            }
+            src->peer_asked |= bit;
+            if (can) src->peer_direct |= bit;
         }
+        const bool direct = bit && (src->peer_direct & bit);
+        snprintf(src->gather_path, sizeof src->gather_path, direct ? "device %d -> device %d: hipMemcpyPeerAsync with peer access enabled (direct link)"
+                                                                   : "device %d -> device %d: hipMemcpyPeerAsync WITHOUT peer access (staged by the runtime)", src->device, dst->device);
         what = "hipMemcpyPeerAsync";
         e = hipMemcpyPeerAsync((char*)dst->d_fb + off, dst->device, (const char*)src->d_fb + off, src->device, bytes, src->stream);
     } else if (e == hipSuccess) {
+        snprintf(src->gather_path, sizeof src->gather_path, "device %d -> device %d: same device, hipMemcpyAsync device to device", src->device, dst->device);
         what = "hipMemcpyAsync";
         e = hipMemcpyAsync((char*)dst->d_fb + off, (const char*)src->d_fb + off, bytes, hipMemcpyDeviceToDevice, src->stream);
     }
@@ -1196,6 +1340,8 @@ int srt_gather_band(srt_context* dst, srt_context* src, int row_begin, int row_e
     if (e != hipSuccess) return fail(dst, e == hipErrorOutOfMemory ? SRT_ERR_OOM : SRT_ERR_HIP, "srt_gather_band: %s: %s", what, hipGetErrorString(e));
     return SRT_OK;
 }
+
+const char* srt_gather_path(const srt_context* src) { return src ? src->gather_path : "(null context)"; }
 
 int srt_write_accumulator(srt_context* ctx, const float* src_rgba) {
     if (!ctx || !src_rgba) return SRT_ERR_INVALID_ARG;

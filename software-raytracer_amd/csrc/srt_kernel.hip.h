@@ -100,7 +100,10 @@ struct KernelParams {
     // cost-ordered dispatch: workgroup i of the launch works on tile block wg_order[i] (NULL: i); every
     // wave adds its run time (10 ns ticks of the constant clock) to wg_cost[block] (NULL: not recorded) for the order of the next launch
     const uint32_t* wg_order;
-    uint32_t* wg_cost;
+    uint32_t* wg_cost;       // [2 * wg_blocks]: the blocks' wave time, then the blocks' WORK (their own loop counts under work_w, in 64 wave instructions)
+    uint32_t wg_blocks;
+    uint32_t work_w[7];      // weights of TALLY_STEPS, GROUPS, NODE_ROUNDS, LEAF_TRIPS, MESH_PHASES, WAVES, UNTRACED_WAVES (srt_capi.hip, ProbeWeights)
+    unsigned long long* work_counter;  // SRT_RENDER_COUNT_WORK: [TALLY_ALL] totals of the launch (NULL: not counted)
     float4* accumulator;
     uint32_t* framebuffer;
     unsigned long long* ray_counter;
@@ -109,7 +112,7 @@ struct KernelParams {
 // internal KernelParams.flags bit (srt_render sets it): progressive-block launch whose lanes stand for steps x steps
 // blocks instead of pixels — a lane traces its block's ray and writes all of the block's pixels
 constexpr uint32_t KF_BLOCK_GRID = 0x10u;
-constexpr uint32_t KF_BOXES_FINITE = 0x20u;  // (srt_set_scene found every box centre and half size finite: closest_hit's NaN-free slab test)
+constexpr uint32_t KF_BOXES_FINITE = 0x20u;  // (srt_set_scene found every box centre and half size below 1e29 in size: closest_hit's NaN-free slab test)
 constexpr uint32_t SRT_MESH_ORDER_W = 6u;  // block_cost_kernel: ordering cost of a ray that ends on a mesh, in analytic rays (as the balance cost)
 constexpr int TILE_W = 8, TILE_H = 8;       // per wavefront
 constexpr int WG_TILES_X = 2, WG_TILES_Y = 2;  // waves per workgroup
@@ -274,8 +277,9 @@ __device__ __forceinline__ BoxRay box_ray_setup(V3 rd) {
     return b;
 }
 // Box::iBox (Object.hpp:173-200) distance part; t1 out for the normal.
-// NO_NAN: the caller has seen that origin and direction of every lane that counts are finite and that the scene's boxes are; then
-// no slab distance is a NaN (slopes are +-1e8 at most in size, or +0 for a zero component) and `a > b ? a : b` differs from the
+// NO_NAN: the caller has seen that the direction of every lane that counts is finite and that its origin and the scene's boxes are
+// below 1e29 in size; then no slab distance is a NaN or an infinity on the way (slopes are +-1e8 at most in size, or +0 for a zero
+// component; products below 2e37, sums below 4e37) and `a > b ? a : b` differs from the
 // hardware's max / min only in which zero comes out of (+0, -0) — and tN, tF go nowhere but into comparisons and, from 0.01 up,
 // into the result: one v_max3_f32 / v_min3_f32 instead of four compare-and-select pairs.
 template <bool NO_NAN>
@@ -299,21 +303,34 @@ __device__ __forceinline__ V3 ibox_normal(const BoxRay& br, V3 t1) {
     return v3((br.sgn.x * -1) * s1.x * s2.x, (br.sgn.y * -1) * s1.y * s2.y, (br.sgn.z * -1) * s1.z * s2.z);
 }
 
-// The balance probe (PROBE instantiation of pathtrace_kernel, srt_estimate_row_costs): wave-uniform counts of what the loops of
-// the path pool and of closest_hit do for a tile — the trip counts the kernel's instruction count (and, for meshes, its memory
-// round trips) follow from.  The host weighs them (srt_capi.hip, ProbeWeights).  Every other instantiation gets the empty
-// Tally: no code.  (Also counted in round 3 and dropped, their fitted weights came out at nothing: second halves of the sphere
-// test, trips of the scatter loop, fold iterations, boxes with a valid hit, steps with an environment lookup, traced and
-// untraced pixels; rays per mesh phase.)
+// Wave-uniform counts of what the loops of the path pool and of closest_hit do for a tile — the trip counts the kernel's
+// instruction count (and, for meshes, its memory round trips) follow from.  Kept by the TALLY instantiations only (scalar adds on
+// wave-uniform values; the steady-state kernels get the empty Tally: no code, no scalar registers).  Three things are made from them:
+//   * the balance probe (PROBE instantiation, srt_estimate_row_costs): the first TALLY_N words per 16 x 16 block, weighed by the
+//     host (srt_capi.hip, ProbeWeights);
+//   * the launch-shape record (round 4): the launch that records block costs for the dispatch order — the first launch of a band
+//     after the scene or the camera changed — also records every block's WORK, the same weights applied to its own counts
+//     (KernelParams.work_w), and the sample-chunk rule of srt_render reads only that: counts, not times, so the same inputs give
+//     the same launch shape in every run;
+//   * SRT_RENDER_COUNT_WORK: the launch's totals (srt_get_work_counts), from which bench.py prices the EXECUTED lane-operations of
+//     its roofline line.
+// (Also counted in round 3 and dropped, their fitted weights came out at nothing: second halves of the sphere test, trips of the
+// scatter loop, fold iterations, boxes with a valid hit, steps with an environment lookup, traced and untraced pixels; rays per
+// mesh phase.)
 enum {
     TALLY_STEPS = 0,       // pool steps (one closest_hit call of the whole wave each)
     TALLY_GROUPS,          // groups of four clustered spheres put through the exact test (a round of 64 items: K / 4)
     TALLY_NODE_ROUNDS,     // mesh traversal: node rounds
-    TALLY_LEAF_TRIPS,      // mesh traversal: triangle trips of the leaf rounds
+    TALLY_LEAF_TRIPS,      // mesh traversal: triangle trips of the leaf rounds (one triangle test per lane each)
     TALLY_MESH_PHASES,     // mesh traversal: phases started
     TALLY_WAVES,           // waves (each stages the scene and traces its pixels' primary rays — once per sample chunk in a real launch)
     TALLY_UNTRACED_WAVES,  // waves with an untraced pixel (the sample-independent colour is folded sample by sample, once per wave)
-    TALLY_N = 8
+    TALLY_NODE_TESTS,      // mesh traversal: child boxes tested per lane, summed over the node rounds (8, 4, 2 or 1 a round)
+    TALLY_N = 8,           // words per block of the balance probe's record (tools/band_fit.py, tools/emulate_ranks.py)
+    TALLY_CALLS = 8,       // closest_hit calls (pool steps + the primary ray's): every one runs all uniform spheres and all boxes
+    TALLY_BOUND_CALLS,     // ... of which went through the cluster bounds (all of them, unless a lane's direction was not unit length)
+    TALLY_ITEMS,           // (ray, cluster) pairs that survived the bounds: the USEFUL lanes of the exact rounds
+    TALLY_ALL = 12
 };
 template <bool ON>
 struct Tally {
@@ -321,7 +338,7 @@ struct Tally {
 };
 template <>
 struct Tally<true> {
-    unsigned c[TALLY_N];
+    unsigned c[TALLY_ALL];
     __device__ __forceinline__ void add(int i, unsigned v) { c[i] += v; }
 };
 
@@ -363,8 +380,9 @@ __device__ __forceinline__ void hit_unkey(unsigned long long k, float& t, int& p
 //      fetch the ray with __shfl, run the EXACT sphere arithmetic and merge through a 64-bit
 //      LDS atomicMin on hit_key — so the wave does sum(pairs)/64 rounds, not max-per-lane.
 //   3. boxes: every lane, exact arithmetic.
-template <bool MESH, bool PROBE = false>
-__device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, V3 o, V3 d, bool active, int defer_min, bool& deferred, Tally<PROBE>& tally SRT_PROF_PARAM) {
+template <bool MESH, bool TALLY = false>
+__device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, V3 o, V3 d, bool active, int defer_min, bool& deferred, Tally<TALLY>& tally SRT_PROF_PARAM) {
+    tally.add(TALLY_CALLS, 1u);
     float best = __builtin_inff();
     int bp = -1;
     // exact sphere test of ray (ro, rd) against four spheres; updates (tb, pb) with the tie rule.
@@ -438,6 +456,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
         const float dd = __builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x));
         const bool unit = fabsf(dd - 1.0f) <= 1e-6f;  // false for NaN
         if (__builtin_amdgcn_ballot_w64(active && !unit) == 0ull) {
+            tally.add(TALLY_BOUND_CALLS, 1u);
             const float o1 = (fabsf(o.x) + fabsf(o.y)) + fabsf(o.z);
             unsigned long long mask = 0ull;
             for (int k = 0; k < S.nc; ++k) {  // phase 1: conservative cluster bounds, uniform reads
@@ -466,6 +485,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                 SRT_STAT(7, st_active);
             }
 #endif
+            tally.add(TALLY_ITEMS, (unsigned)total);
             if (total > 0 && total <= WORK_MAX) {
                 const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
                 // the lane's own best so far enters the merge slot
@@ -533,10 +553,11 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
     const int nsT = S.nsT, nb = S.nb;
     if (nb > 0) {
         br = box_ray_setup(d);
-        // (a NaN or infinity anywhere in a ray that counts — the sum is then not finite; so is, harmlessly, a sum that overflows —
-        // sends the wave through the comparisons as the reference writes them)
-        const float fin = ((o.x + o.y) + o.z) + ((d.x + d.y) + d.z);
-        const bool no_nan = (P.flags & KF_BOXES_FINITE) != 0 && __builtin_amdgcn_ballot_w64(active && !(fabsf(fin) < __builtin_inff())) == 0ull;
+        // (a NaN or infinity anywhere in a ray that counts, or an origin so far out that a slab product could overflow — |o|_1 at or
+        // beyond 1e29, the bound srt_set_scene holds the boxes to as well, srt_scene_image.h — sends the wave through the
+        // comparisons as the reference writes them)
+        const float omag = (fabsf(o.x) + fabsf(o.y)) + fabsf(o.z), dsum = (d.x + d.y) + d.z;
+        const bool no_nan = (P.flags & KF_BOXES_FINITE) != 0 && __builtin_amdgcn_ballot_w64(active && !(omag < 1e29f && fabsf(dsum) < __builtin_inff())) == 0ull;
         auto boxes = [&](auto tag) {
             for (int j = 0; j < nb; ++j) {
                 const float4 c = S.box_c(j), hs = S.box_h(j);
@@ -706,6 +727,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                                 takeN = takeN < room ? takeN : room;
                             }
                             nN -= takeN;  // the items [nN, nN + takeN) are popped
+                            tally.add(TALLY_NODE_TESTS, 8u >> logP);
 #ifdef SRT_STATS
                             if (SRT_STATS == 1) {
                                 SRT_STAT(2, 1);
@@ -1061,11 +1083,15 @@ __device__ __forceinline__ Lds make_lds(const KernelParams& P, float4* lds, int 
 // store the colours, in sample order, as coalesced rows of P.sample_rows and fold_kernel does the fold.
 // PROBE: the balance probe of srt_estimate_row_costs — the same pool over the frame's first few samples, nothing read from or
 // written to the frame; instead every wave adds its Tally to the TALLY_N words of its block in P.wg_cost.
-template <int MIN_WAVES, bool MESH, bool SCENE_LDS = true, bool MULTI = false, bool DEFER = false, bool PROBE = false>
+// TALLY: the instantiation that keeps the wave-uniform loop counts (see Tally): the recording launch of a band, and launches with
+// SRT_RENDER_COUNT_WORK.  Same results; a few scalar adds per pool step and some scalar-register pressure the steady-state
+// instantiations do not pay.
+template <int MIN_WAVES, bool MESH, bool SCENE_LDS = true, bool MULTI = false, bool DEFER = false, bool PROBE = false, bool TALLY_ = false>
 __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const KernelParams P) {
     static_assert(!PROBE || (!MULTI && !DEFER), "the probe runs the full-tile pool");
+    constexpr bool TALLY = TALLY_ || PROBE;
     extern __shared__ float4 lds_scene[];
-    Tally<PROBE> tally{};
+    Tally<TALLY> tally{};
 #if defined(SRT_STATS) && SRT_STATS == 3
     Prof prof;
     prof.last = (long long)__builtin_readcyclecounter();
@@ -1242,7 +1268,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
 
     // ---- primary hit: identical for every sample ------------------------------------
     bool parked = false;  // path pool: this lane's ray waits for a mesh phase (see closest_hit)
-    const Hit h0 = closest_hit<MESH>(S, P, cam, dir0, true, 1, parked, tally SRT_PROF_ARG);
+    const Hit h0 = closest_hit<MESH, TALLY>(S, P, cam, dir0, true, 1, parked, tally SRT_PROF_ARG);
 
     const bool reset = (P.flags & 1u) != 0;
     // samples of this workgroup: all of them, or chunk blockIdx.z of the launch
@@ -1268,10 +1294,8 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     const bool pix_traced = in_range && h0.prim >= 0 && B > 0 && !preview;  // (the same for every pixel of a block)
     const bool traced = pix_traced && is_leader;
     float4 untraced_val = make_float4(0, 0, 0, 0);
-    if constexpr (PROBE) {
-        tally.add(TALLY_UNTRACED_WAVES, __builtin_amdgcn_ballot_w64(in_range && !pix_traced) != 0ull ? 1u : 0u);
-        tally.add(TALLY_WAVES, 1u);
-    }
+    tally.add(TALLY_UNTRACED_WAVES, __builtin_amdgcn_ballot_w64(in_range && !pix_traced) != 0ull ? 1u : 0u);
+    tally.add(TALLY_WAVES, 1u);
     if (!PROBE && in_range && !pix_traced && (!DEFER || blockIdx.z == 0)) {  // (chunked: once, by the first chunk, for all samples)
         RGB c;
         if (h0.prim < 0) {
@@ -1479,7 +1503,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 // entries a slot that fell behind stalls the tail of the tile (lanes idle while its last samples run one after
                 // the other); serving the laggards first keeps the slots level, ~5 % fewer pool steps (tests/pool_stats.py)
                 rot = (rot + 23) & 63;
-                const unsigned long long lagm = __builtin_amdgcn_ballot_w64(can && __umul24(own_next, (unsigned)n_hit) <= handed);
+                const unsigned long long lagm = __builtin_amdgcn_ballot_w64(can && (unsigned)__umul24(own_next, (unsigned)n_hit) <= handed);
                 const unsigned long long restm = canm & ~lagm;
                 // rank inside a tier, counted cyclically from lane `rot`: bits below the lane, minus the bits below `rot`,
                 // plus the whole tier for the lanes that wrapped (all 32-bit: no per-lane 64-bit mask)
@@ -1582,7 +1606,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             // the scan runs in wave-uniform control flow: idle lanes help with other lanes' rays
             // (a mesh phase waits for P.mesh_defer rays (12) — but not for long (P.mesh_wait = 3 steps): where mesh rays are rare a parked ray would hold its lane
             // and, through the ring, its slot for many steps; after P.mesh_wait steps with someone parked the phase runs for whoever is there)
-            const Hit h = closest_hit<MESH>(S, P, o, sray, busy, MESH && park_steps >= P.mesh_wait ? 1 : P.mesh_defer, parked, tally SRT_PROF_ARG);
+            const Hit h = closest_hit<MESH, TALLY>(S, P, o, sray, busy, MESH && park_steps >= P.mesh_wait ? 1 : P.mesh_defer, parked, tally SRT_PROF_ARG);
             if constexpr (MESH) park_steps = __builtin_amdgcn_ballot_w64(busy && parked) != 0ull ? park_steps + 1 : 0;
             if (busy && !(MESH && parked)) {
                 ++rays;
@@ -1652,6 +1676,12 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 if (tally.c[i]) atomicAdd(&P.wg_cost[(size_t)block_id * TALLY_N + i], tally.c[i]);
         return;
     }
+    // SRT_RENDER_COUNT_WORK: what this wave's loops did, added to the launch's totals (srt_get_work_counts)
+    if constexpr (TALLY) {
+        if (P.work_counter && lane == 0)
+            for (int i = 0; i < TALLY_ALL; ++i)
+                if (tally.c[i]) atomicAdd(&P.work_counter[i], (unsigned long long)tally.c[i]);
+    }
     if ((P.flags & 2u) || P.wg_cost) {  // SRT_RENDER_COUNT_RAYS / cost feedback for the dispatch order
         unsigned long long tot = rays;
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
@@ -1663,6 +1693,16 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 const long long dt = (long long)__builtin_amdgcn_s_memrealtime() - t_start;
                 atomicAdd(&P.wg_cost[block_id], (dt > 0 && dt < (1ll << 28)) ? (uint32_t)dt : (uint32_t)(tot < (1ull << 24) ? tot * 16ull : (1ull << 28)));
             }
+        }
+        // ... and the block's WORK, for the launch-shape rule (srt_render): the wave's own counts under the balance probe's weights,
+        // in units of 64 wave instructions.  Counts, not times: the same in every run.
+        if constexpr (TALLY) if (P.wg_cost && lane == 0) {
+            const unsigned long long w = (unsigned long long)P.work_w[0] * tally.c[TALLY_STEPS] + (unsigned long long)P.work_w[1] * tally.c[TALLY_GROUPS] +
+                                         (unsigned long long)P.work_w[2] * tally.c[TALLY_NODE_ROUNDS] + (unsigned long long)P.work_w[3] * tally.c[TALLY_LEAF_TRIPS] +
+                                         (unsigned long long)P.work_w[4] * tally.c[TALLY_MESH_PHASES] + (unsigned long long)P.work_w[5] * tally.c[TALLY_WAVES] +
+                                         (unsigned long long)P.work_w[6] * tally.c[TALLY_UNTRACED_WAVES];
+            const unsigned long long u = (w + 63ull) >> 6;
+            atomicAdd(&P.wg_cost[P.wg_blocks + block_id], (uint32_t)(u < (1ull << 28) ? u : (1ull << 28)));
         }
     }
 }

@@ -62,6 +62,13 @@
 
 namespace srt {
 
+// Magnitude bound behind the kernel's NaN-free box slab test (closest_hit, KF_BOXES_FINITE): with every box centre and half size
+// and the ray origin's |.|_1 below it, o - c is below 2e29 in size, the slab slopes are at most 1e8 (or exactly 0), so every
+// product is below 2e37 and every sum of two below 4e37 — finite, hence never inf - inf or 0 * inf: no slab distance is a NaN.
+// (Round 3 asked only for FINITE numbers, which does not exclude an overflow to infinity on the way: 3.4e30-sized coordinates
+// under a slope of 1e8.  Such scenes now take the comparisons as the reference writes them.)
+constexpr float SRT_BOX_NO_NAN_BOUND = 1e29f;
+
 constexpr int SRT_CONST_ROWS = 46, SRT_CONST_ENV_ROW = 32, SRT_CONST_COEF_ROW = 36;  // (rows 36-45: srt_pow_coef, 20 doubles)
 
 struct SceneLayout {
@@ -75,7 +82,9 @@ struct SceneLayout {
     int off_bounds = 0, off_box = 0, off_mat = 0;
     int total_vec4 = 0;
     int n_spheres = 0;  // real spheres (for statistics)
-    bool boxes_finite = true;  // every box centre and half size is a finite number (the kernel's NaN-free slab test relies on it)
+    // every box centre and half size is a number of magnitude below SRT_BOX_NO_NAN_BOUND (the kernel's NaN-free slab test relies on
+    // it, together with the same bound on the ray's origin: see closest_hit)
+    bool boxes_finite = true;
 };
 
 // the four environment rows of the constants block (colours through Color's clamping constructor, Common.hpp:253-262)
@@ -287,7 +296,7 @@ inline SceneLayout build_scene_image(const srt_object* objects, size_t count, bo
         const srt_object& o = objects[boxes[j]];
         img[L.off_box + 2 * j] = make_float4(o.position[0], o.position[1], o.position[2], 0.0f);
         img[L.off_box + 2 * j + 1] = make_float4(o.half_size[0], o.half_size[1], o.half_size[2], 0.0f);
-        for (int a = 0; a < 3; ++a) L.boxes_finite = L.boxes_finite && std::isfinite(o.position[a]) && std::isfinite(o.half_size[a]);
+        for (int a = 0; a < 3; ++a) L.boxes_finite = L.boxes_finite && std::fabs(o.position[a]) < SRT_BOX_NO_NAN_BOUND && std::fabs(o.half_size[a]) < SRT_BOX_NO_NAN_BOUND;  // (NaN: false)
         put_material(L.nsT + (int)j, boxes[j]);
     }
     for (size_t m = 0; m < meshobjs.size(); ++m) put_material(L.nsT + L.nb + (int)m, meshobjs[m]);

@@ -24,6 +24,7 @@ EXPORTS = [
     "srt_host_renderer_read_accumulator", "srt_host_renderer_stats", "srt_host_renderer_handle",
     "srt_host_multi_create", "srt_host_multi_destroy", "srt_host_multi_set_scene", "srt_host_multi_configure",
     "srt_host_multi_render_samples", "srt_host_multi_read_framebuffer", "srt_host_multi_band", "srt_host_multi_stats", "srt_host_multi_balance", "srt_host_multi_use_equal_bands",
+    "srt_host_multi_use_manual_bands", "srt_host_multi_set_auto_balance_min_samples", "srt_host_multi_set_row_band",
 ]
 
 _lib = None
@@ -106,6 +107,9 @@ def load_library():
     L.srt_host_multi_stats.argtypes = [vp, C.POINTER(Stats), C.c_int]
     L.srt_host_multi_balance.argtypes = [vp]
     L.srt_host_multi_use_equal_bands.argtypes = [vp, C.c_int]
+    L.srt_host_multi_use_manual_bands.argtypes = [vp, C.c_int]
+    L.srt_host_multi_set_auto_balance_min_samples.argtypes = [vp, C.c_uint32]
+    L.srt_host_multi_set_row_band.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.srt_host_renderer_handle.restype = vp
     _lib = L
     return L
@@ -339,9 +343,20 @@ class MultiRenderer:
         self._ck(self.L.srt_host_multi_balance(self._h))
 
     def use_equal_bands(self, equal=True):
-        """north_star's literal equal bands instead of the default split (bands of equal estimated cost, made at the first
-        render_samples after the scene / camera / settings change)."""
+        """north_star's literal equal bands instead of the default split (bands of equal estimated cost, made by the first
+        render_samples after the scene / camera / bounces change whose count is at least 32 per device)."""
         self._ck(self.L.srt_host_multi_use_equal_bands(self._h, 1 if equal else 0))
+
+    def use_manual_bands(self, manual=True):
+        """Leave the bands set through set_row_band() alone (without this the automatic split replaces them)."""
+        self._ck(self.L.srt_host_multi_use_manual_bands(self._h, 1 if manual else 0))
+
+    def set_row_band(self, i, begin, end):
+        self._ck(self.L.srt_host_multi_set_row_band(self._h, int(i), int(begin), int(end)))
+
+    def set_auto_balance_min_samples(self, per_device):
+        """The automatic split probes only for requests of at least this many samples per device (default 32)."""
+        self._ck(self.L.srt_host_multi_set_auto_balance_min_samples(self._h, int(per_device)))
 
     def band(self, i):
         b, e = C.c_int(), C.c_int()

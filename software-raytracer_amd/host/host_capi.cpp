@@ -239,6 +239,9 @@ int srt_host_multi_read_framebuffer(srt_host_multi* h, void* dst, size_t pitch) 
 int srt_host_multi_band(srt_host_multi* h, int i, int* begin, int* end) { SRT_HOST_TRY(h, h->r->Band((size_t)i, begin, end)) }
 int srt_host_multi_balance(srt_host_multi* h) { SRT_HOST_TRY(h, h->r->BalanceBands()) }
 int srt_host_multi_use_equal_bands(srt_host_multi* h, int equal) { SRT_HOST_TRY(h, h->r->UseEqualBands(equal != 0)) }
+int srt_host_multi_use_manual_bands(srt_host_multi* h, int manual) { SRT_HOST_TRY(h, h->r->UseManualBands(manual != 0)) }
+int srt_host_multi_set_auto_balance_min_samples(srt_host_multi* h, uint32_t per_device) { SRT_HOST_TRY(h, h->r->SetAutoBalanceMinSamples(per_device)) }
+int srt_host_multi_set_row_band(srt_host_multi* h, int i, int begin, int end) { SRT_HOST_TRY(h, h->r->part((size_t)i).SetRowBand(begin, end)) }
 int srt_host_multi_stats(srt_host_multi* h, srt_stats* out, int n) {
     SRT_HOST_TRY(h, {
         std::vector<srt_stats> st = h->r->Stats();

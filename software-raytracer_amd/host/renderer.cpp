@@ -163,6 +163,10 @@ MultiGpuRenderer::~MultiGpuRenderer() {
 }
 
 void MultiGpuRenderer::Band(size_t i, int* begin, int* end) const {
+    if (manual_bands_) {  // the caller's own bands (part(i).SetRowBand)
+        parts_[i]->RowBand(begin, end);
+        return;
+    }
     *begin = bounds_[i];
     *end = bounds_[i + 1];
 }
@@ -172,6 +176,19 @@ void MultiGpuRenderer::EqualBands() {
     for (int k = 0; k <= n; ++k) bounds_[(size_t)k] = k * q + (k < r ? k : r);
     for (int k = 0; k < n; ++k) parts_[(size_t)k]->SetRowBand(bounds_[(size_t)k], bounds_[(size_t)k + 1]);
     split_pending_ = false;
+    balanced_ = false;
+}
+
+static bool same_vec(const Vec3& a, const Vec3& b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+
+// the balanced split in force was made for this scene, camera, field of view and bounce count (the probe's inputs that matter;
+// its seed moves the estimate by noise only)
+bool MultiGpuRenderer::SplitIsCurrent() const {
+    if (!balanced_ || parts_.empty()) return false;
+    const PathTraceRenderer& p0 = *parts_[0];
+    return split_scene_generation_ == scene_generation_ && split_fov_ == p0.FOV && split_bounces_ == p0.MAXBOUNCES &&
+           same_vec(split_camera_.position, p0.camera.position) && same_vec(split_camera_.right, p0.camera.right) &&
+           same_vec(split_camera_.up, p0.camera.up) && same_vec(split_camera_.forward, p0.camera.forward);
 }
 
 void MultiGpuRenderer::UseEqualBands(bool equal) {
@@ -206,10 +223,14 @@ void MultiGpuRenderer::BalanceBands() {
     bounds_[(size_t)n] = height_;
     for (int k = 0; k < n; ++k) parts_[(size_t)k]->SetRowBand(bounds_[(size_t)k], bounds_[(size_t)k + 1]);
     split_pending_ = false;
+    balanced_ = true;
+    split_scene_generation_ = scene_generation_;
+    split_camera_ = p0.camera, split_fov_ = p0.FOV, split_bounces_ = p0.MAXBOUNCES;
 }
 
 void MultiGpuRenderer::SetScene(const Scene& scene) {
     for (PathTraceRenderer* p : parts_) p->SetScene(scene);
+    ++scene_generation_;
     split_pending_ = true;
 }
 
@@ -234,11 +255,20 @@ void MultiGpuRenderer::Invalidate() {
 }
 
 void MultiGpuRenderer::RenderSamples(uint32_t count, bool count_rays) {
-    if (split_pending_) {  // the accumulation starts over: the moment rows may change owners
-        if (equal_bands_) EqualBands();
-        else BalanceBands();
-        split_pending_ = false;
+    if (split_pending_ && !manual_bands_) {  // the accumulation starts over: the moment rows may change owners
+        // The balance probe is the work of about 8 sample-frames on ONE device, synchronous: worth it only for a request that is a
+        // multiple of that per device, and not again for inputs the split in force was made for (renderer.hpp).
+        if (equal_bands_) {
+            EqualBands();
+        } else if (SplitIsCurrent()) {
+            // (same scene, camera, field of view and bounces: a new seed or an Invalidate() alone does not move the costs)
+        } else if ((unsigned long long)count >= (unsigned long long)auto_min_samples_ * parts_.size()) {
+            BalanceBands();
+        } else if (balanced_) {
+            EqualBands();  // a split made for other inputs is worth no more than equal bands, and the request is too small to probe for
+        }
     }
+    split_pending_ = false;
     for (PathTraceRenderer* p : parts_) p->RenderSamples(count, count_rays);  // asynchronous: one stream per part
     for (size_t i = 1; i < parts_.size(); ++i) {                              // the one gather
         int b, e;

@@ -82,6 +82,7 @@ class PathTraceRenderer {
     void SetEnvironment(const srt_environment& env);
     // restrict rendering to memory rows [begin,end) (multi-GPU row stripes)
     void SetRowBand(int begin, int end);
+    void RowBand(int* begin, int* end) const { *begin = row_begin_, *end = row_end_; }
     // doSetFrame = true: any camera / object / setting edit (:391,453,461,469,476,497,522)
     void Invalidate() { doSetFrame_ = true; }
 
@@ -141,16 +142,28 @@ class MultiGpuRenderer {
     // memory-row band of part i.  Equal bands (the first height % N parts take one more row) until the first
     // RenderSamples; from then on, by default, bands of equal ESTIMATED cost (below).
     void Band(size_t i, int* begin, int* end) const;
-    // Bands of equal ESTIMATED cost for the current scene, camera and bounce count (srt_estimate_row_costs on part 0:
-    // a device-side probe that runs the kernel's path pool over a quarter of the pixels for 32 samples and counts its loop
-    // trips — about 8 sample-frames of work, deterministic), boundaries on multiples of 2 rows (8 and 16 were tried: too coarse for
-    // the 48..64-row floor bands of an 8-way 1080p split).  Equal bands leave the GPUs
-    // that own sky idle: on Scene1 the slowest of 8 equal bands takes 2.2x the average.  This is the DEFAULT
-    // split: RenderSamples applies it whenever the accumulation (re)starts — after SetScene, Configure or Invalidate, when every
-    // band starts from sample 1 anyway — so a caller never has to ask.  UseEqualBands(true) goes back to north_star's literal
-    // equal bands; BalanceBands() itself stays callable.
+    // Bands of equal ESTIMATED cost for the current scene, camera and bounce count (srt_estimate_row_costs on part 0: a
+    // device-side probe that runs the kernel's path pool over a quarter of the pixels for the frame's first 32 samples and counts
+    // its loop trips — the work of about 8 sample-frames on ONE device, synchronous, deterministic), boundaries on multiples of 2
+    // rows (8 and 16 were tried: too coarse for the 48..64-row floor bands of an 8-way 1080p split).  Equal bands
+    // leave the GPUs that own sky idle: on Scene1 the slowest of 8 equal bands takes 2.2x the average.
+    //
+    // Who decides the bands (round 4; the round-3 class re-split before EVERY restarted accumulation, whatever it cost):
+    //   * automatic (default): RenderSamples(count) makes the balanced split when the accumulation (re)starts — after SetScene,
+    //     Configure, Invalidate: every band starts from sample 1 then anyway — AND the request is worth the probe:
+    //     count >= AutoBalanceMinSamples() x devices (default 32 per device: the probe's 8 sample-frames on one device are then
+    //     at most a quarter of what the devices are about to do).  A smaller request — a preview frame, a camera move with a few
+    //     samples per frame — keeps the bands it has (equal ones at first).  A split made for the same scene, camera, field of
+    //     view and bounce count is reused: a new seed or an Invalidate() alone never probes again.
+    //   * BalanceBands(): the balanced split now, kept until scene, camera, field of view or bounces change.
+    //   * UseEqualBands(true): north_star's literal equal bands, never re-split.
+    //   * UseManualBands(true): the bands the caller gave the parts through part(i).SetRowBand() are left alone (the caller
+    //     answers for their covering the frame); without it the automatic split REPLACES such bands.
     void BalanceBands();
     void UseEqualBands(bool equal);
+    void UseManualBands(bool manual) { manual_bands_ = manual; }
+    void SetAutoBalanceMinSamples(uint32_t per_device) { auto_min_samples_ = per_device; }
+    uint32_t AutoBalanceMinSamples() const { return auto_min_samples_; }
 
     void SetScene(const Scene& scene);  // replicated: every device gets its own copy (a few KB; meshes: a few MB)
     void SetEnvironment(const srt_environment& env);
@@ -170,7 +183,15 @@ class MultiGpuRenderer {
     std::vector<int> bounds_;  // band i = memory rows [bounds_[i], bounds_[i + 1])
     int width_, height_;
     bool equal_bands_ = false;    // UseEqualBands(true)
-    bool split_pending_ = true;   // the accumulation restarts with the next RenderSamples: (re)make the split then
+    bool manual_bands_ = false;   // UseManualBands(true)
+    bool split_pending_ = true;   // the accumulation restarts with the next RenderSamples: the moment rows may change owners
+    uint32_t auto_min_samples_ = 32;
+    // what the current balanced split was made for (valid while balanced_): a split for the same inputs is reused
+    bool balanced_ = false;
+    unsigned long long scene_generation_ = 0, split_scene_generation_ = 0;
+    Transform split_camera_{};
+    int split_fov_ = 0, split_bounces_ = 0;
+    bool SplitIsCurrent() const;
     void EqualBands();
 };
 

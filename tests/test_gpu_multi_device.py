@@ -23,6 +23,8 @@ def test_multi_renderer_equals_single_device_and_oracle(srt, oracle, name, n_par
     m.configure(fov=55, max_bounces=6, seed=3)
     if equal:
         m.use_equal_bands()
+    else:
+        m.set_auto_balance_min_samples(0)  # (the automatic split probes only for requests of >= 32 samples per device; these are smaller)
     m.render_samples(spp, count_rays=True)
     bands = [m.band(i) for i in range(n_parts)]
     assert bands[0][0] == 0 and bands[-1][1] == h and all(bands[i][1] == bands[i + 1][0] for i in range(n_parts - 1))
@@ -82,6 +84,76 @@ def test_balanced_bands_equal_the_single_device_frame(srt):
     assert [m.band(i) for i in range(n_parts)] == equal and np.array_equal(m.framebuffer(), pt.framebuffer())
     m.close()
     pt.close()
+
+
+def test_automatic_split_is_gated_on_the_work_it_balances(srt):
+    """Round 4 (advice): the balance probe costs about 8 sample-frames on ONE device, synchronously.  The automatic split pays it
+    only for a request of at least 32 samples per device, reuses a split made for the same scene / camera / bounces (a new seed
+    does not probe again), and leaves bands alone that the caller set by hand when told so."""
+    w, h, n_parts = 640, 360, 4
+    scene = srt.host.Scene(scene_path("Scene1"))
+    objs, n = scene.objects_copy()
+    pt = srt.PathTracer(w, h)
+    pt.set_scene(objs, n)
+    pt.set_camera(srt.default_camera())
+    m = srt.host.MultiRenderer([0] * n_parts, w, h)
+    m.set_scene(scene)
+    m.configure(fov=55, max_bounces=8, seed=0)
+    equal = [m.band(i) for i in range(n_parts)]
+    m.render_samples(4)                                   # 4 < 32 x 4: no probe, the equal bands stay
+    assert [m.band(i) for i in range(n_parts)] == equal
+    pt.render(spp=4, bounces=8, seed=0)
+    assert np.array_equal(m.framebuffer(), pt.framebuffer())
+    m.configure(fov=55, max_bounces=8, seed=0)            # the accumulation restarts ...
+    m.render_samples(128)                                 # ... with a request worth the probe: balanced bands
+    bands = [m.band(i) for i in range(n_parts)]
+    assert bands != equal and bands[0][1] - bands[0][0] > bands[-1][1] - bands[-1][0]
+    pt.render(spp=128, bounces=8, seed=0)
+    assert np.array_equal(m.framebuffer(), pt.framebuffer())
+    m.configure(fov=55, max_bounces=8, seed=7)            # only the seed changed: the split is reused, also for a small request
+    m.render_samples(2)
+    assert [m.band(i) for i in range(n_parts)] == bands
+    pt.render(spp=2, bounces=8, seed=7)
+    assert np.array_equal(m.framebuffer(), pt.framebuffer())
+    m.configure(fov=55, max_bounces=3, seed=7)            # other bounces and a small request: not worth a probe, and the old split
+    m.render_samples(2)                                   # is worth no more than equal bands
+    assert [m.band(i) for i in range(n_parts)] == equal
+    # bands set by hand are left alone under use_manual_bands (and REPLACED without it, as documented)
+    hand = [(0, 100), (100, 180), (180, 300), (300, 360)]
+    m.use_manual_bands()
+    for i, (a, b) in enumerate(hand):
+        m.set_row_band(i, a, b)
+    m.configure(fov=55, max_bounces=8, seed=0)
+    m.render_samples(256)
+    assert [m.band(i) for i in range(n_parts)] == hand
+    pt.render(spp=256, bounces=8, seed=0)
+    assert np.array_equal(m.framebuffer(), pt.framebuffer())
+    m.close()
+    pt.close()
+
+
+def test_gather_reports_the_way_it_went(srt):
+    """srt_gather_path: on a one-GPU box every gather is a same-device copy; the text is what the first multi-GPU run will
+    report about peer access (the cross-device ways have never run here)."""
+    w, h = 256, 128
+    scene = srt.host.Scene(scene_path("Scene1"))
+    objs, n = scene.objects_copy()
+    a, b = srt.PathTracer(w, h), srt.PathTracer(w, h)
+    assert a.gather_path() == "no gather yet"
+    for t in (a, b):
+        t.set_scene(objs, n)
+        t.set_camera(srt.default_camera())
+    a.render(spp=2, bounces=4, seed=0, rows=(0, 64))
+    b.render(spp=2, bounces=4, seed=0, rows=(64, 128))
+    a.gather_band_from(b, (64, 128))
+    assert "same device" in b.gather_path() and a.gather_path() == "no gather yet"
+    ref = srt.PathTracer(w, h)
+    ref.set_scene(objs, n)
+    ref.set_camera(srt.default_camera())
+    ref.render(spp=2, bounces=4, seed=0)
+    assert np.array_equal(a.framebuffer(), ref.framebuffer())
+    for t in (a, b, ref):
+        t.close()
 
 
 def test_balance_probe_leaves_the_frame_alone(srt, oracle):

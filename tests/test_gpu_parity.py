@@ -75,7 +75,8 @@ def test_random_large_scenes(srt, oracle, nsph, nbox):
     pt.close()
 
 
-@pytest.mark.parametrize("case", ["inf half size", "nan centre", "inf camera", "finite"])
+@pytest.mark.parametrize("case", ["inf half size", "nan centre", "inf camera", "finite", "huge box 3e30", "huge box 2e38", "huge centre 5e33",
+                                  "camera at 1e30", "camera at 3e38", "box just under the bound"])
 def test_boxes_with_non_finite_numbers(srt, oracle, case):
     """The box slab test has a NaN-free form (v_max3 / v_min3) that the kernel may only take when the scene's boxes and every ray
     that counts are finite; anything else goes through the comparisons as the reference writes them.  Scenes and cameras on
@@ -89,11 +90,28 @@ def test_boxes_with_non_finite_numbers(srt, oracle, case):
         objs.append(dict(type=oracle.OBJ_BOX, position=(3, 1, 8), half_size=(inf, 0.5, 0.5), base=(.5, .5, .5)))
     if case == "nan centre":
         objs.append(dict(type=oracle.OBJ_BOX, position=(nan, 1, 8), half_size=(0.5, 0.5, 0.5), base=(.5, .5, .5)))
+    # round 4 (advice): FINITE is not enough for the NaN-free form — o - c or a slab product can overflow to infinity on the way
+    # (slopes reach 1e8) and -inf + inf is a NaN the reference's comparisons propagate and v_max3 / v_min3 drop.  The kernel now
+    # asks for magnitudes below 1e29 (boxes: srt_set_scene; origins: per wave); these cases lie on both sides of that bound.
+    if case == "huge box 3e30":
+        objs.append(dict(type=oracle.OBJ_BOX, position=(0, 0, 9), half_size=(3e30, 3.4e30, 3e30), base=(.5, .5, .5)))
+    if case == "huge box 2e38":
+        objs.append(dict(type=oracle.OBJ_BOX, position=(1, 2, 9), half_size=(2e38, 0.5, 2e38), base=(.5, .7, .5)))
+    if case == "huge centre 5e33":
+        objs.append(dict(type=oracle.OBJ_BOX, position=(5e33, -5e33, 5e33), half_size=(6e33, 6e33, 6e33), base=(.6, .5, .5)))
+    if case == "box just under the bound":
+        objs.append(dict(type=oracle.OBJ_BOX, position=(9e28, 0, 0), half_size=(9.5e28, 9e28, 9e28), base=(.6, .5, .7)))
     oarr, n = oracle.make_objects(objs)
     cam, ocam = srt.default_camera(), oracle.default_camera()
     if case == "inf camera":
         cam.position = (C.c_float * 3)(0.0, inf, 0.0)
         ocam.position = (C.c_float * 3)(0.0, inf, 0.0)
+    if case == "camera at 1e30":
+        cam.position = (C.c_float * 3)(1e30, 0.5, -1e30)
+        ocam.position = (C.c_float * 3)(1e30, 0.5, -1e30)
+    if case == "camera at 3e38":
+        cam.position = (C.c_float * 3)(0.0, 3e38, 0.0)
+        ocam.position = (C.c_float * 3)(0.0, 3e38, 0.0)
     w, h = 96, 54
     pt = srt.PathTracer(w, h)
     pt.set_scene(C.cast(oarr, C.POINTER(srt.Object)), n)

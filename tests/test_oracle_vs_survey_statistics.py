@@ -82,3 +82,66 @@ def test_random_draws_per_sample(oracle, name):
     assert abs(got - DRAWS_8[name]) <= 0.025 * DRAWS_8[name] + 0.05, "%s: oracle %.3f draws/sample, survey %.3g" % (name, got, DRAWS_8[name])
     # the same probe's rays agree with the frame-wide figure too
     assert abs(tot_r / float(cnt) - RBAR_8[name]) <= 0.025 * RBAR_8[name]
+
+
+# share of the primary rays that hit an object (measured on the unmodified reference)
+PRIMARY_HIT = {"Scene1": (0.56, 0.006), "Scene_indirect": (0.999, 0.0006)}  # published figure, half a unit of its last digit + 1 %
+
+
+@pytest.mark.parametrize("name", sorted(PRIMARY_HIT))
+def test_share_of_primary_rays_that_hit(oracle, name):
+    """No random numbers involved: with ONE bounce every traced pixel casts exactly one more ray, so rays = pixels + primary hits.
+    "56 % of primaries hit" (Scene1) / "99.9 %" (Scene_indirect) are the survey's figures from the real reference."""
+    arr, n = _scene(oracle, name)
+    _, _, rays = oracle.render(arr, n, oracle.default_environment(), oracle.default_camera(55), W, H, spp=1, bounces=1, seed=0, pow_mode=oracle.POW_LIBM)
+    share = rays / float(W * H) - 1.0
+    published, half_digit = PRIMARY_HIT[name]
+    assert abs(share - published) <= 0.01 * published + half_digit, "%s: oracle %.4f of the primaries hit, the survey saw %.3g" % (name, share, published)
+
+
+def test_degenerate_ray_cross_in_box_scenes(oracle):
+    """SURVEY §7 'hard parts', seen in the survey's render of the real reference: sign() returns 0 for a zero component
+    (Common.hpp:328-333), which degenerates iBox's slab test (Object.hpp:175-186: m = 0, so t1 = t2 = 0 on that axis and tF <= 0
+    rejects) — a ray whose direction has an exactly zero x or y component misses EVERY box.  With the camera at the origin those
+    are the primary rays of column W / 2 and of row H / 2, so Box scenes show a one-pixel cross there.  Known answer on the oracle:
+    in Scene_indirect's closed room the neighbours of the cross see walls (boxes), the cross itself sees what lies behind."""
+    import ctypes as C
+
+    arr, n = _scene(oracle, "Scene_indirect")
+    objs = oracle.load_scene_json_py(scene_path("Scene_indirect"))
+    is_box = [o["type"] == oracle.OBJ_BOX for o in objs]
+    cam = oracle.default_camera(55)
+    L = oracle.lib()
+    f3 = C.c_float * 3
+
+    def primary(x, y):
+        d, nn, p, t = f3(), f3(), f3(), C.c_float()
+        L.srt_oracle_ray_direction(C.byref(cam), W, H, x, y, d)
+        return L.srt_oracle_closest(arr, n, f3(0, 0, 0), d, nn, p, C.byref(t)), tuple(d)
+
+    col_boxes = off_boxes = row_boxes = 0
+    for y in range(0, H, 7):
+        idx, d = primary(W // 2, y)
+        assert d[0] == 0.0                                     # nX = (W/2)/W*2 - 1 = 0 exactly (Raytracer.cpp:109)
+        col_boxes += idx >= 0 and is_box[idx]
+        for dx in (-1, 1):
+            idx, d = primary(W // 2 + dx, y)
+            assert d[0] != 0.0
+            off_boxes += idx >= 0 and is_box[idx]
+    for x in range(0, W, 7):
+        idx, d = primary(x, H // 2)
+        assert d[1] == 0.0
+        row_boxes += idx >= 0 and is_box[idx]
+    assert col_boxes == 0 and row_boxes == 0                   # the cross: no primary ray on it ever reports a box
+    assert off_boxes >= 0.25 * 2 * len(range(0, H, 7))         # one pixel beside it, the rays that pass the sphere grid end on the room's walls (30 % of the rows)
+    nbr_boxes = 0
+    for x in range(0, W, 7):
+        idx, _ = primary(x, H // 2 + 1)
+        nbr_boxes += idx >= 0 and is_box[idx]
+    assert nbr_boxes >= 0.7 * len(range(0, W, 7))              # ... and one row beside the horizontal bar most rays do (78 %)
+    # ... and it is visible in the frame: the centre column differs from both neighbours wherever they see a wall
+    fb, _, _ = oracle.render(arr, n, oracle.default_environment(), cam, W, H, spp=1, bounces=0, seed=0, pow_mode=oracle.POW_LIBM,
+                             cols=(W // 2 - 1, W // 2 + 2))
+    col = fb[:, W // 2 - 1:W // 2 + 2]
+    differs = ((col[:, 1] != col[:, 0]) & (col[:, 1] != col[:, 2])).mean()
+    assert differs > 0.2

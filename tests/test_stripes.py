@@ -61,11 +61,23 @@ WORKER = textwrap.dedent('''
         fb, acc, _ = O.render(arr, n, env, cam, W, H, spp=2, bounces=4, seed=0, rows=(rb, re), threads=2)
         frame = torch.zeros((H, W), dtype=torch.int32)
         frame[rb:re] = torch.from_numpy(fb.view(np.int32))[rb:re]
-        st.gather_bands(frame, bands, rank, world, dist, method="padded" if mode.endswith("padded") else "p2p")
+        # (the padded gather's buffers are made ONCE and reused by every step, as bench.py does: the second step gathers
+        # another frame through the same buffers; the sending side is a view of the frame, the rows behind a band are never read)
+        bufs = st.GatherBuffers(frame, bands, rank, world) if mode.endswith("padded") else None
+        st.gather_bands(frame, bands, rank, world, dist, method="padded" if mode.endswith("padded") else "p2p", buffers=bufs)
         if rank == 0:
             full, _, _ = O.render(arr, n, env, cam, W, H, spp=2, bounces=4, seed=0, threads=2)
             assert np.array_equal(frame.numpy().view(np.uint32), full), mode
             print("OK", mode, bands)
+        if bufs is not None:
+            frame[:] = -1                                   # a second step through the same buffers: a recognisable frame
+            frame[rb:re] = 1000 * rank + torch.arange(rb, re, dtype=torch.int32)[:, None]
+            st.gather_bands(frame, bands, rank, world, dist, method="padded", buffers=bufs)
+            if rank == 0:
+                for k, (x, y) in enumerate(bands):
+                    assert torch.equal(frame[x:y, 0], 1000 * k + torch.arange(x, y, dtype=torch.int32)), (mode, k)
+                assert bufs.rows == max(y - x for x, y in bands) and all(s + bufs.rows <= H for s in bufs.start)
+                print("REUSED", mode)
     dist.barrier()
     dist.destroy_process_group()
 ''')

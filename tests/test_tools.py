@@ -28,3 +28,48 @@ def test_probe_weights_in_the_library_match_the_fit_notes():
     for name, key in (("group", "groups"), ("leaf_trip", "leaf_trips"), ("wave", "waves")):
         v = float(re.search(r"\b%s = ([0-9.]+)" % name, src).group(1))
         assert '"%s": %d' % (key, round(v)) in notes, (name, v)
+
+
+def _write_round(tmp_path, trace_kernels, trace_grids, pass_kernels, pass_grids, layers, frac=0.6, same=True):
+    import json
+
+    d = tmp_path / "r99"
+    d.mkdir(exist_ok=True)
+    k = lambda names: {n: {"calls": 3, "mean_ms": 1.0, "min_ms": 1.0, "max_ms": 1.0} for n in names}
+    (d / "kernel_durations_w.json").write_text(json.dumps({"timed": {"kernels": k(trace_kernels), "grid_threads_total": trace_grids, "launches": 3}}))
+    (d / "pmc_w.json").write_text(json.dumps({"passes": {g: {"kernels": k(pass_kernels), "grid_threads_total": pass_grids} for g in ("sq1", "hbm_r")}}))
+    (d / "bench_w.json").write_text(json.dumps({"config": {"launch_shape": {"grid_layers": layers, "tile_rows": 8, "same_as_timed_launches": same}},
+                                                "roofline": {"frac": frac}}) + "\n")
+    return str(d)
+
+
+def test_profile_check_catches_profiles_of_different_launches(tmp_path):
+    """tools/profile_check.py: a kernel trace, the counter passes and the bench line of a workload must describe the same launches —
+    kernel instantiation, total grid, grid layers — and the bench line's roofline.frac must be a fraction.  (Round 3's c5_rank4of8
+    set mixed a sample-chunked trace with unchunked counter passes: the launch shape depended on run-time timers.)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import profile_check as PC
+
+    one = ["srt::pathtrace_kernel<4, true, true, false, false, false>"]
+    chunked = ["srt::fold_kernel", "srt::pathtrace_kernel<4, true, true, false, true, false>"]
+    assert PC.check_round(_write_round(tmp_path, one, [1044480], one, [1044480], 1)) == []
+    assert PC.check_round(_write_round(tmp_path, chunked, [9400320], chunked, [9400320], 9)) == []
+    probs = PC.check_round(_write_round(tmp_path, chunked, [9400320], one, [1044480], 1))  # round 3's c5_rank4of8
+    assert any("counter pass sq1 ran" in p for p in probs) and any("grids of" in p for p in probs) and any("grid layer" in p for p in probs)
+    assert any("roofline.frac" in p for p in PC.check_round(_write_round(tmp_path, one, [1], one, [1], 1, frac=1.31)))
+    assert any("another shape" in p for p in PC.check_round(_write_round(tmp_path, one, [1], one, [1], 1, same=False)))
+
+
+def test_committed_profiles_describe_the_same_launches():
+    """The newest committed round from r04 on passes tools/profile_check.py (r01-r03 predate the deterministic launch shape)."""
+    import glob
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import profile_check as PC
+
+    rounds = sorted(d for d in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]")) if os.path.basename(d) >= "r04" and glob.glob(os.path.join(d, "kernel_durations_*.json")))
+    if not rounds:
+        import pytest
+
+        pytest.skip("no profiles/r04+ yet")
+    assert PC.check_round(rounds[-1]) == []

@@ -109,6 +109,15 @@ def summarise(launches):
         if l["fold"]:
             per.setdefault(l["fold"]["kernel"], []).append((l["fold"]["end"] - l["fold"]["start"]) * 1e-6)
     tot = [launch_ms(l) for l in launches]
+    def threads(g):
+        n = 1
+        for v in g:
+            n *= max(int(v), 1)
+        return n
+
     return {"launches": len(launches), "launch_ms_mean": sum(tot) / len(tot), "launch_ms_min": min(tot), "launch_ms_max": max(tot),
             "dispatch_ids": [l["main"]["id"] for l in launches],
+            # total threads of the launches' pathtrace dispatches (x * y * z: the kernel trace reports the three sizes, a counter pass
+            # their product) — with the kernel names, what tools/profile_check.py compares between a trace and a counter pass
+            "grid_threads_total": sorted({threads(l["main"]["grid"]) for l in launches}),
             "kernels": {k: {"calls": len(v), "mean_ms": sum(v) / len(v), "min_ms": min(v), "max_ms": max(v)} for k, v in sorted(per.items())}}
