@@ -73,6 +73,13 @@ constexpr DevSwitches k_dev_switches{};
 constexpr const DevSwitches& dev_switches() { return k_dev_switches; }
 #endif
 
+// the launch-shape record of one block of tiles: what its four waves' loops did, weighed (ProbeWeights) — `sum` over the waves
+// (the wave slots the block occupies over time), `longest` the heaviest wave (how long the workgroup holds its slot)
+struct BlockWork {
+    float sum, longest;
+};
+constexpr size_t REC_WORDS = 1 + 4 * srt::TALLY_N;  // per block in the cost record: wave time, then TALLY_N counts for each of the four waves
+
 struct HostCamera {
     srt_camera cam;
     bool set = false;
@@ -129,14 +136,15 @@ struct srt_context {
     unsigned order_gx = 0, order_gy = 0;  // grid the order in d_wg_order was made for (0 = none)
     unsigned rec_gx = 0, rec_gy = 0;      // grid of the recording in flight
     bool recording = false;               // a cost copy is in flight (ev_cost)
-    bool rec_has_work = false;            // ... and its second half holds the blocks' work (the recording launch was a TALLY instantiation)
+    bool rec_has_work = false;            // ... and behind the times it holds the waves' loop counts (the recording launch was a TALLY instantiation)
+    double rec_step_w = 0.0;              // what a pool step of the recorded launch weighs (probe_step_weight: depends on the scene's layout)
     int work_layout[4] = {0, 0, 0, 0};    // of the last launch: uniform spheres, clusters, spheres per cluster, boxes (srt_get_work_counts)
     bool order_stale = true;              // scene / camera changed since the costs were recorded
     // the launch-shape record (round 4): every block's WORK as the recording launch counted it — loop trips under the balance
     // probe's weights, not times — so the sample-chunk rule is a deterministic function of scene, camera, band and call history
-    std::vector<uint32_t> work;           // per block of the recorded grid, sorted by decreasing work (what the fill simulation walks)
+    std::vector<BlockWork> work;          // per block of the recorded grid, longest-running first (what the fill simulation walks)
     double work_sum = 0.0;                // of the record (0: none), its maximum and its grid:
-    uint32_t work_max = 0;                //   the dearest block: how uneven the blocks are decides the number of sample chunks
+    double work_max = 0.0;                //   the dearest block: how uneven the blocks are decides the number of sample chunks
     unsigned cost_gx = 0, cost_gy = 0;
     int band_y0 = -1, band_rows = -1;     // the row band the order, the recording and the cost figures above belong to
     bool estimate_stale = true;           // the scene changed since the order was last estimated on the device
@@ -584,26 +592,26 @@ static double probe_block_cost(const uint32_t* c, const srt::KernelParams& K, co
            w.mesh_phase * c[srt::TALLY_MESH_PHASES] + w.wave * c[srt::TALLY_WAVES] + w.untraced_wave * c[srt::TALLY_UNTRACED_WAVES];
 }
 
-// How full a launch of `layers` sample chunks keeps `slots` resident workgroups, from the recorded block works alone: the
-// workgroups are started layer by layer, dearest block first (the cost order of the real dispatch), each on the slot that frees
-// first, and run for work / layers; the result is sum of the run times / (slots x the time the last one ends).  A deterministic
-// stand-in for what round 3 read off the recorded launch's event time (wave time / launch time x resident waves): that figure
-// moved with the clock and flipped launch shapes near its threshold.
-static double simulate_fill(const std::vector<uint32_t>& sorted_work, int layers, int slots) {
-    if (sorted_work.empty() || slots < 1 || layers < 1) return 1.0;
+// How full a launch of `layers` sample chunks keeps the wave slots of `slots` resident workgroups, from the recorded work alone:
+// the workgroups are started layer by layer, longest block first (the cost order of the real dispatch), each on the slot that
+// frees first; a workgroup holds its slot for its heaviest wave's work / layers, and its four waves occupy their wave slots for
+// their own work / layers; the result is occupied wave-slot time / (wave slots x the time the last workgroup ends).  A
+// deterministic stand-in for what round 3 read off the recorded launch's event time (wave time / launch time x resident waves):
+// that figure moved with the clock and flipped launch shapes near its threshold.
+static double simulate_fill(const std::vector<BlockWork>& by_length, int layers, int slots) {
+    if (by_length.empty() || slots < 1 || layers < 1) return 1.0;
     std::vector<double> heap((size_t)slots, 0.0);  // min-heap of the slots' finish times
     auto cmp = [](double a, double b) { return a > b; };
-    double sum = 0.0, end = 0.0;
+    double occupied = 0.0, end = 0.0;
     for (int z = 0; z < layers; ++z)
-        for (uint32_t w : sorted_work) {
-            const double d = (double)w / (double)layers;
+        for (const BlockWork& b : by_length) {
             std::pop_heap(heap.begin(), heap.end(), cmp);
-            heap.back() += d;
+            heap.back() += (double)b.longest / (double)layers;
             end = heap.back() > end ? heap.back() : end;
             std::push_heap(heap.begin(), heap.end(), cmp);
-            sum += d;
+            occupied += (double)b.sum / (double)layers;
         }
-    return end > 0.0 ? sum / (end * (double)slots) : 1.0;
+    return end > 0.0 ? occupied / (end * (double)slots * (srt::WG_TILES_X * srt::WG_TILES_Y)) : 1.0;
 }
 
 // A recording launch's cost copy has completed: make the dispatch order of the following launches from the blocks' wave TIMES
@@ -628,14 +636,28 @@ static int consume_record(srt_context* ctx) {
     }
     uint32_t lo = 0xFFFFFFFFu, hi = 0;
     for (size_t i = 0; i < n; ++i) lo = ctx->h_wg_cost[i] < lo ? ctx->h_wg_cost[i] : lo, hi = ctx->h_wg_cost[i] > hi ? ctx->h_wg_cost[i] : hi;
-    // the launch-shape record: the second half of the copy (present when the recording launch kept its counts)
-    ctx->work_sum = 0.0, ctx->work_max = 0, ctx->work.clear();
+    // the launch-shape record: behind the times, the loop counts of every wave (present when the recording launch kept them)
+    ctx->work_sum = 0.0, ctx->work_max = 0.0, ctx->work.clear();
     if (ctx->rec_has_work) {
-        const uint32_t* wk = ctx->h_wg_cost + n;
-        ctx->work.assign(wk, wk + n);
-        std::sort(ctx->work.begin(), ctx->work.end(), [](uint32_t a, uint32_t b) { return a > b; });
-        for (uint32_t w : ctx->work) ctx->work_sum += (double)w;
-        ctx->work_max = ctx->work.empty() ? 0u : ctx->work.front();
+        const ProbeWeights pw;
+        const double w[srt::TALLY_N] = {ctx->rec_step_w, pw.group, pw.node_round, pw.leaf_trip, pw.mesh_phase, pw.wave, pw.untraced_wave, 0.0};
+        const uint32_t* cnt = ctx->h_wg_cost + n;
+        ctx->work.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            double sum = 0.0, longest = 0.0;
+            for (int v = 0; v < 4; ++v) {
+                const uint32_t* c = cnt + (i * 4 + (size_t)v) * srt::TALLY_N;
+                double x = 0.0;
+                for (int k = 0; k < srt::TALLY_N; ++k) x += w[k] * (double)c[k];
+                sum += x;
+                longest = x > longest ? x : longest;
+            }
+            ctx->work[i] = BlockWork{(float)sum, (float)longest};
+            ctx->work_sum += sum;
+            ctx->work_max = sum > ctx->work_max ? sum : ctx->work_max;
+        }
+        // (ties in `longest` keep the block order: std::stable_sort, so the record is the same vector in every run)
+        std::stable_sort(ctx->work.begin(), ctx->work.end(), [](const BlockWork& a, const BlockWork& b) { return a.longest > b.longest; });
         ctx->cost_gx = ctx->rec_gx, ctx->cost_gy = ctx->rec_gy;
     }
 #ifdef SRT_DEV
@@ -649,11 +671,25 @@ static int consume_record(srt_context* ctx) {
         else
             (void)hipGetLastError();
         const double slots = (double)ctx->cu_count * (ctx->mesh_image.n_tris > 0 ? 3.0 : 4.0);
-        fprintf(stderr, "record: %zu blocks grid %u x %u | TIME dearest %u sum %.0f ratio %.3f fill %.3f (%.3f ms) | WORK dearest %u sum %.0f ratio %.3f", n, ctx->rec_gx, ctx->rec_gy,
+        fprintf(stderr, "record: %zu blocks grid %u x %u | TIME dearest %u sum %.0f ratio %.3f fill %.3f (%.3f ms) | WORK dearest %.0f sum %.0f ratio %.3f", n, ctx->rec_gx, ctx->rec_gy,
                 hi, tsum, tsum > 0 ? hi * slots / tsum : 0.0, tfill, ms, ctx->work_max, ctx->work_sum, ctx->work_sum > 0 ? ctx->work_max * slots / ctx->work_sum : 0.0);
         const int wslots = ctx->cu_count * (ctx->mesh_image.n_tris > 0 ? 4 : 5);
         for (int c : {1, 2, 3, 4, 6, 8}) fprintf(stderr, " fill(%d)=%.3f", c, simulate_fill(ctx->work, c, wslots));
         fprintf(stderr, "\n");
+    }
+    if (const char* dump = getenv("SRT_DUMP_RECORD")) {  // development aid (tools/shape_fit.py): the raw record, appended as one binary blob
+        if (FILE* f = fopen(dump, "ab")) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end) != hipSuccess) ms = 0.0f, (void)hipGetLastError();
+            uint32_t ms_bits, sw_bits;
+            const float sw = (float)ctx->rec_step_w;
+            memcpy(&ms_bits, &ms, 4), memcpy(&sw_bits, &sw, 4);
+            const uint32_t head[10] = {0x53525452u, ctx->rec_gx, ctx->rec_gy, (uint32_t)ctx->band_y0, (uint32_t)ctx->band_rows, ms_bits, sw_bits,
+                                       (uint32_t)ctx->cu_count, ctx->mesh_image.n_tris > 0 ? 1u : 0u, ctx->rec_has_work ? 1u : 0u};
+            fwrite(head, 4, 10, f);
+            fwrite(ctx->h_wg_cost, 4, n * REC_WORDS, f);
+            fclose(f);
+        }
     }
 #endif
     const double scale = hi > lo ? (double)(NB - 1) / (double)(hi - lo) : 0.0;
@@ -781,7 +817,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             c = ratio < 0.85 ? (K.n_tris > 0 ? 1 : 2) : (long long)ceil(ratio * 100.0 / (double)dev_switches().chunk_beta);
             shape_source = 1;
 #ifdef SRT_DEV
-            if (getenv("SRT_DEBUG_CHUNKS")) fprintf(stderr, "chunks: dearest %u sum %.0f blocks %lld slots %.0f ratio %.3f -> c %lld\n", ctx->work_max, ctx->work_sum, wg8, slots, ratio, c);
+            if (getenv("SRT_DEBUG_CHUNKS")) fprintf(stderr, "chunks: dearest %.0f sum %.0f blocks %lld slots %.0f ratio %.3f -> c %lld\n", ctx->work_max, ctx->work_sum, wg8, slots, ratio, c);
 #endif
         }
         // Analytic scenes, round 3 (five resident workgroups per CU, ring of two): at least ten rounds of workgroups, whatever the
@@ -897,10 +933,10 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             ctx->recording = false;
             // an optimisation must not be able to fail a render: if anything here cannot be had (pinned host
             // memory, for one), the handle simply keeps the natural order from now on
-            // (cost buffers: the blocks' wave times, then the blocks' work)
-            const bool ok = hipMalloc((void**)&ctx->d_wg_cost, 2 * nwg * 4) == hipSuccess && hipMalloc((void**)&ctx->d_wg_order, nwg * 4) == hipSuccess &&
+            // (cost buffers: the blocks' wave times, then the loop counts of every wave of every block)
+            const bool ok = hipMalloc((void**)&ctx->d_wg_cost, REC_WORDS * nwg * 4) == hipSuccess && hipMalloc((void**)&ctx->d_wg_order, nwg * 4) == hipSuccess &&
                             hipMalloc((void**)&ctx->d_wg_est, 2 * nwg * 4) == hipSuccess &&  // raw + smoothed
-                            hipHostMalloc((void**)&ctx->h_wg_cost, 2 * nwg * 4, hipHostMallocDefault) == hipSuccess &&
+                            hipHostMalloc((void**)&ctx->h_wg_cost, REC_WORDS * nwg * 4, hipHostMallocDefault) == hipSuccess &&
                             hipHostMalloc((void**)&ctx->h_wg_order, nwg * 4, hipHostMallocDefault) == hipSuccess &&
                             (ctx->ev_cost || hipEventCreateWithFlags(&ctx->ev_cost, hipEventDisableTiming) == hipSuccess) &&
                             (ctx->ev_order || hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming) == hipSuccess);
@@ -935,7 +971,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
         }
         if (ctx->order_gx == grid.x && ctx->order_gy == grid.y) K.wg_order = ctx->d_wg_order;
         if (ctx->order_stale || ctx->order_gx != grid.x || ctx->order_gy != grid.y) {  // (no record is in flight here: it was waited for above)
-            SRT_HIP(ctx, hipMemsetAsync(ctx->d_wg_cost, 0, 2 * nwg * 4, ctx->stream));
+            SRT_HIP(ctx, hipMemsetAsync(ctx->d_wg_cost, 0, REC_WORDS * nwg * 4, ctx->stream));
             K.wg_cost = ctx->d_wg_cost;
             K.wg_blocks = (uint32_t)nwg;
             record = true;
@@ -948,14 +984,9 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     const bool tally = (record || want_work) && in_lds;
     ctx->count_work = want_work;
     ctx->count_work_valid = want_work && tally;
-    if (tally) {
-        const ProbeWeights pw;
-        const double wv[7] = {probe_step_weight(K, pw), pw.group, pw.node_round, pw.leaf_trip, pw.mesh_phase, pw.wave, pw.untraced_wave};
-        for (int i = 0; i < 7; ++i) K.work_w[i] = (uint32_t)(wv[i] + 0.5);
-        if (want_work) {
-            SRT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, srt::TALLY_ALL * sizeof(unsigned long long), ctx->stream));
-            K.work_counter = ctx->d_work;
-        }
+    if (tally && want_work) {
+        SRT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, srt::TALLY_ALL * sizeof(unsigned long long), ctx->stream));
+        K.work_counter = ctx->d_work;
     }
     SRT_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     // instantiation: mesh or not, scene image in LDS or HBM, full tiles / small tiles (multi-sample
@@ -1001,11 +1032,12 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     SRT_HIP(ctx, hipGetLastError());
     SRT_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
     if (record) {
-        SRT_HIP(ctx, hipMemcpyAsync(ctx->h_wg_cost, ctx->d_wg_cost, 2 * nwg * 4, hipMemcpyDeviceToHost, ctx->stream));
+        SRT_HIP(ctx, hipMemcpyAsync(ctx->h_wg_cost, ctx->d_wg_cost, REC_WORDS * nwg * 4, hipMemcpyDeviceToHost, ctx->stream));
         SRT_HIP(ctx, hipEventRecord(ctx->ev_cost, ctx->stream));
         ctx->recording = true;
         ctx->rec_gx = grid.x, ctx->rec_gy = grid.y;
         ctx->rec_has_work = tally;
+        ctx->rec_step_w = probe_step_weight(K, ProbeWeights());
         ctx->order_stale = false;
     }
     ctx->launched = true;

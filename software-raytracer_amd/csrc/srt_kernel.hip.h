@@ -100,9 +100,8 @@ struct KernelParams {
     // cost-ordered dispatch: workgroup i of the launch works on tile block wg_order[i] (NULL: i); every
     // wave adds its run time (10 ns ticks of the constant clock) to wg_cost[block] (NULL: not recorded) for the order of the next launch
     const uint32_t* wg_order;
-    uint32_t* wg_cost;       // [2 * wg_blocks]: the blocks' wave time, then the blocks' WORK (their own loop counts under work_w, in 64 wave instructions)
+    uint32_t* wg_cost;       // [wg_blocks] the blocks' wave time, then (TALLY instantiations) [wg_blocks][4 waves][TALLY_N] the waves' loop counts
     uint32_t wg_blocks;
-    uint32_t work_w[7];      // weights of TALLY_STEPS, GROUPS, NODE_ROUNDS, LEAF_TRIPS, MESH_PHASES, WAVES, UNTRACED_WAVES (srt_capi.hip, ProbeWeights)
     unsigned long long* work_counter;  // SRT_RENDER_COUNT_WORK: [TALLY_ALL] totals of the launch (NULL: not counted)
     float4* accumulator;
     uint32_t* framebuffer;
@@ -309,8 +308,8 @@ __device__ __forceinline__ V3 ibox_normal(const BoxRay& br, V3 t1) {
 //   * the balance probe (PROBE instantiation, srt_estimate_row_costs): the first TALLY_N words per 16 x 16 block, weighed by the
 //     host (srt_capi.hip, ProbeWeights);
 //   * the launch-shape record (round 4): the launch that records block costs for the dispatch order — the first launch of a band
-//     after the scene or the camera changed — also records every block's WORK, the same weights applied to its own counts
-//     (KernelParams.work_w), and the sample-chunk rule of srt_render reads only that: counts, not times, so the same inputs give
+//     after the scene or the camera changed — also records the counts of every wave of every block; the host weighs them like the
+//     probe's (ProbeWeights) and the sample-chunk rule of srt_render reads only that: counts, not times, so the same inputs give
 //     the same launch shape in every run;
 //   * SRT_RENDER_COUNT_WORK: the launch's totals (srt_get_work_counts), from which bench.py prices the EXECUTED lane-operations of
 //     its roofline line.
@@ -1694,15 +1693,13 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 atomicAdd(&P.wg_cost[block_id], (dt > 0 && dt < (1ll << 28)) ? (uint32_t)dt : (uint32_t)(tot < (1ull << 24) ? tot * 16ull : (1ull << 28)));
             }
         }
-        // ... and the block's WORK, for the launch-shape rule (srt_render): the wave's own counts under the balance probe's weights,
-        // in units of 64 wave instructions.  Counts, not times: the same in every run.
+        // ... and what the wave's loops did, for the launch-shape rule (srt_render): the first TALLY_N counts of every wave of the
+        // block (the four waves of a workgroup apart: a workgroup holds its slot until its slowest wave ends; the layers of a
+        // sample-chunked launch add up).  Counts, not times: the same in every run.  The host weighs them (ProbeWeights).
         if constexpr (TALLY) if (P.wg_cost && lane == 0) {
-            const unsigned long long w = (unsigned long long)P.work_w[0] * tally.c[TALLY_STEPS] + (unsigned long long)P.work_w[1] * tally.c[TALLY_GROUPS] +
-                                         (unsigned long long)P.work_w[2] * tally.c[TALLY_NODE_ROUNDS] + (unsigned long long)P.work_w[3] * tally.c[TALLY_LEAF_TRIPS] +
-                                         (unsigned long long)P.work_w[4] * tally.c[TALLY_MESH_PHASES] + (unsigned long long)P.work_w[5] * tally.c[TALLY_WAVES] +
-                                         (unsigned long long)P.work_w[6] * tally.c[TALLY_UNTRACED_WAVES];
-            const unsigned long long u = (w + 63ull) >> 6;
-            atomicAdd(&P.wg_cost[P.wg_blocks + block_id], (uint32_t)(u < (1ull << 28) ? u : (1ull << 28)));
+            uint32_t* rec = P.wg_cost + P.wg_blocks + ((size_t)block_id * (WG_TILES_X * WG_TILES_Y) + wave) * TALLY_N;
+            for (int i = 0; i < TALLY_N; ++i)
+                if (tally.c[i]) atomicAdd(&rec[i], tally.c[i]);
         }
     }
 }

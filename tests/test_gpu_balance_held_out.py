@@ -1,0 +1,50 @@
+"""The balance probe on a scene it was NOT fitted on (round 4, the verdict's item 5): srt_estimate_row_costs -> a 4-way split of
+Scene3 (boxes, mirror wall, emitters; the weights of ProbeWeights were fitted on Scene1-based configs 3 and 5) at 1080p and 256
+spp; every band rendered by a context of its own, as a rank would.  mean / slowest of the measured kernel times must reach 0.85
+(the committed emulation, profiles/emulated_ranks.json "held out: ...", has the figures for N = 2 / 4 / 8 and three more scenes).
+A timing assertion with a wide margin: equal bands of this frame sit near 0.6."""
+import importlib
+import statistics
+
+import pytest
+
+from conftest import scene_path
+
+pytestmark = pytest.mark.gpu
+
+
+def test_probe_split_balances_a_held_out_scene(srt):
+    stripes = importlib.import_module("software-raytracer_amd.stripes")
+    w, h, spp, bounces, n = 1920, 1080, 256, 8, 4
+    scene = srt.host.Scene(scene_path("Scene3"))
+    objs, cnt = scene.objects_copy()
+
+    def tracer():
+        pt = srt.PathTracer(w, h)
+        pt.set_scene(objs, cnt)
+        pt.set_camera(srt.default_camera())
+        return pt
+
+    pt = tracer()
+    cost = pt.estimate_row_costs(bounces, 0)
+    pt.close()
+    bands = stripes.partition_rows(h, n, cost, align=2)
+    assert len({b - a for a, b in bands}) > 1  # not the equal split
+
+    def band_ms(rows):
+        t = tracer()
+        ms = []
+        for _ in range(6):
+            t.render(spp=spp, bounces=bounces, seed=0, rows=rows)
+            ms.append(t.stats().kernel_ms)
+        t.close()
+        return statistics.median(ms[2:])
+
+    ms = [band_ms(b) for b in bands]
+    eff = sum(ms) / n / max(ms)
+    eq = [band_ms(b) for b in stripes.partition_rows(h, n)]
+    eff_eq = sum(eq) / n / max(eq)
+    print("Scene3 1080p 256 spp, N = 4: probe split %s ms %s -> mean / slowest %.3f; equal bands %s -> %.3f" %
+          (bands, ["%.2f" % v for v in ms], eff, ["%.2f" % v for v in eq], eff_eq))
+    assert eff >= 0.85, (bands, ms)
+    assert max(ms) <= max(eq) * 1.02  # and the balanced split's slowest rank is no slower than the equal split's

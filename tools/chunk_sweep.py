@@ -6,7 +6,7 @@ import argparse, importlib, json, os, statistics, subprocess, sys, tempfile
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
-ap.add_argument("config", type=int, choices=[2, 3, 5, 6, 7, 8])
+ap.add_argument("config", type=int, choices=[2, 3, 4, 5, 6, 7, 8])
 ap.add_argument("--bands", required=True)
 ap.add_argument("--chunks", default="0,256,128,64")
 ap.add_argument("--child", action="store_true")
@@ -21,7 +21,7 @@ if not a.child:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), str(a.config), "--bands", a.bands, "--child"], env=env, capture_output=True, text=True, timeout=600)
         print("chunk %-4s %s" % (c if int(c) else "rule", r.stdout.strip() or r.stderr[-400:]), flush=True)
     sys.exit(0)
-CFG = {2: ("Scene1", 0, 1920, 1080, 32, 8), 8: ("Scene1", 0, 1920, 1080, 64, 8), 3: ("Scene1", 0, 1920, 1080, 512, 8), 5: ("Scene1", 224, 3840, 2160, 1024, 16), 6: ("Scene_indirect", 0, 1920, 1080, 512, 8), 7: ("Scene3", 0, 1920, 1080, 512, 8)}
+CFG = {2: ("Scene1", 0, 1920, 1080, 32, 8), 4: ("Scene1", 224, 1920, 1080, 64, 8), 8: ("Scene1", 0, 1920, 1080, 64, 8), 3: ("Scene1", 0, 1920, 1080, 512, 8), 5: ("Scene1", 224, 3840, 2160, 1024, 16), 6: ("Scene_indirect", 0, 1920, 1080, 512, 8), 7: ("Scene3", 0, 1920, 1080, 512, 8)}
 scene, mesh, W, H, spp, bounces = CFG[a.config]
 srt = importlib.import_module("software-raytracer_amd")
 srt.capi.use_dev_library()

@@ -8,15 +8,21 @@ import argparse, importlib, json, os, statistics, sys, tempfile
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
-ap.add_argument("config", type=int, choices=[3, 5])
+ap.add_argument("config", help="3 | 5 (the BASELINE configs the balance weights were fitted on) or a HELD-OUT workload: scene3 | scene_indirect | scene2 "
+                                 "(1080p, 512 spp, 8 bounces) | c4_4k (config 4's mesh scene at 3840x2160, 256 spp, 8 bounces)")
 ap.add_argument("--ranks", default="2,4,8")
 ap.add_argument("--modes", default="probe,equal")
 ap.add_argument("--json", default="")
 ap.add_argument("--align", type=int, default=2, help="row alignment of the cost-balanced split")
 ap.add_argument("--weights", default="", help="development: JSON of probe weights; the split is then computed here from the raw counts (development library)")
 a = ap.parse_args()
-CFG = {3: ("Scene1", 0, 1920, 1080, 512, 8), 5: ("Scene1", 224, 3840, 2160, 1024, 16)}
+CFG = {"3": ("Scene1", 0, 1920, 1080, 512, 8), "5": ("Scene1", 224, 3840, 2160, 1024, 16),
+       # held out: never used for the fit of ProbeWeights or for the launch-shape rule (round 4, the verdict's item 5)
+       "scene3": ("Scene3", 0, 1920, 1080, 512, 8), "scene_indirect": ("Scene_indirect", 0, 1920, 1080, 512, 8), "scene2": ("Scene2", 0, 1920, 1080, 512, 8),
+       "c4_4k": ("Scene1", 224, 3840, 2160, 256, 8)}
 scene, mesh, W, H, spp, bounces = CFG[a.config]
+a.config = int(a.config) if a.config.isdigit() else a.config
+label = ("config %d" % a.config) if isinstance(a.config, int) else a.config
 srt = importlib.import_module("software-raytracer_amd")
 stripes = importlib.import_module("software-raytracer_amd.stripes")
 path = os.path.join(ROOT, "software-raytracer_amd", "scenes", scene + ".json")
@@ -74,15 +80,15 @@ else:
     row_cost = pt.estimate_row_costs(bounces, 0)
     pt.close()
 whole = band_ms((0, H))
-print("config %d: whole frame on one GPU %.2f ms" % (a.config, whole), flush=True)
-doc = {"config": a.config, "whole_frame_ms": whole, "splits": [], "probe_rows": probe_rows, "consts": consts, "height": H}
+print("%s: whole frame on one GPU %.2f ms" % (label, whole), flush=True)
+doc = {"config": a.config, "workload": "%s%s %dx%d %d spp %d bounces" % (scene, "+mesh%d" % mesh if mesh else "", W, H, spp, bounces), "whole_frame_ms": whole, "splits": [], "probe_rows": probe_rows, "consts": consts, "height": H}
 for N in (int(v) for v in a.ranks.split(",")):
     for mode in a.modes.split(","):
         bands = stripes.partition_rows(H, N, row_cost if mode == "probe" else None, align=a.align if mode == "probe" else 1)
         ms = [band_ms(b) for b in bands]
         eff = sum(ms) / N / max(ms)
-        print("config %d N=%d %-5s rows %s\n      ms %s | slowest %.2f  mean/slowest %.3f  (whole/N)/slowest %.3f" %
-              (a.config, N, mode, [b[0] for b in bands] + [H], " / ".join("%.2f" % v for v in ms), max(ms), eff, whole / N / max(ms)), flush=True)
+        print("%s N=%d %-5s rows %s\n      ms %s | slowest %.2f  mean/slowest %.3f  (whole/N)/slowest %.3f" %
+              (label, N, mode, [b[0] for b in bands] + [H], " / ".join("%.2f" % v for v in ms), max(ms), eff, whole / N / max(ms)), flush=True)
         doc["splits"].append({"ranks": N, "split": mode, "bands": [list(b) for b in bands], "kernel_ms": ms, "mean_over_slowest": eff, "whole_over_n_over_slowest": whole / N / max(ms)})
 if a.json:
     json.dump(doc, open(a.json, "w"), indent=1)

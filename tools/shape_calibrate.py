@@ -12,7 +12,8 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path
 sys.path.insert(0, ROOT)
 os.environ.setdefault("SRT_DEBUG_CHUNKS", "1")
 cfg = int(sys.argv[1])
-CFG = {3: ("Scene1", 0, 1920, 1080, 512, 8), 4: ("Scene1", 224, 1920, 1080, 64, 8), 5: ("Scene1", 224, 3840, 2160, 1024, 16)}
+CFG = {3: ("Scene1", 0, 1920, 1080, 512, 8), 4: ("Scene1", 224, 1920, 1080, 64, 8), 5: ("Scene1", 224, 3840, 2160, 1024, 16),
+       6: ("Scene_indirect", 0, 1920, 1080, 512, 8), 7: ("Scene3", 0, 1920, 1080, 512, 8), 9: ("Scene1", 224, 3840, 2160, 256, 8)}
 scene, mesh, W, H, spp, bounces = CFG[cfg]
 srt = importlib.import_module("software-raytracer_amd")
 srt.capi.use_dev_library()
@@ -28,7 +29,7 @@ for spec in sys.argv[2].split(","):
     pt = srt.PathTracer(W, H)
     pt.set_meshes(meshes, nm); pt.set_scene(objs, n); pt.set_camera(srt.default_camera())
     print("== config %d rows %d-%d (%d spp, %d bounces)" % (cfg, rb, re, spp, bounces), flush=True)
-    for i in range(4):
+    for i in range(int(os.environ.get('SRT_CAL_LAUNCHES', '4'))):
         pt.render(spp=spp, bounces=bounces, seed=0, rows=(rb, re))
         st = pt.stats()
         sys.stderr.flush()
