@@ -340,6 +340,7 @@ def main():
     st_last = pt.stats()
     rays = st_last.rays
     wc = pt.work_counts().as_dict()
+    counting_launch_ms = float(st_last.kernel_ms)
     shape = {"tile_rows": int(st_last.tile_rows), "grid_layers": int(st_last.sample_chunks), "chunk_samples": int(st_last.chunk_samples),
              "shape_source": "work record of the band's first launch" if st_last.shape_source else "static rule (request and grid)",
              "same_as_timed_launches": (st_last.tile_rows, st_last.sample_chunks, st_last.chunk_samples) == (st_timed.tile_rows, st_timed.sample_chunks, st_timed.chunk_samples)}
@@ -547,13 +548,15 @@ def main():
                 "kernel_ms_last_timed_launch": last_launch_ms,
                 "kernel_ms_cold_first_launch": cold_ms,
                 "kernel_ms_first_launch_warm_clocks": warm_first_ms,
+                "kernel_ms_counting_launch": counting_launch_ms,  # the same launch through the instantiation that keeps the loop counts (untimed)
                 "peak_note": "%sfp32 VALU without FMA credit: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (contraction is forbidden by the bit-exactness contract)" %
                              ("%d GPUs x " % world if world > 1 else ""),
                 "achieved_kind": kind,
                 "counted": wc if world == 1 else {"note": "rank 0's counts; every rank's executed lane-ops in per_rank", **wc},
                 "valu_model": VALU_MODEL,
                 "executed_laneops_per_sample": sum(rank_ex) / sum(p[2] for p in per_rank),
-                "pool_lane_efficiency": (rays - W * (re - rb)) / (64.0 * wc["pool_steps"]) if wc.get("pool_steps") else None,
+                # bounce rays (every ray but the samples' primary ones) per lane-step of the pool: how full its 64 lanes are
+                "pool_lane_efficiency": (rays - local_samples) / (64.0 * wc["pool_steps"]) if wc.get("pool_steps") else None,
                 "rays_per_sample": rbar,
                 "measured_valu_issue_frac": measured_issue,
                 "measured_valu_issue_frac_note": "from profiles/counters.json, NOT from this run: SQ_INSTS_VALU x 64 / the launch time of the rocprofv3 pass "

@@ -584,6 +584,19 @@ struct ProbeWeights {
     double wave = 5830.0;          // per tile: staging, primary rays, ring — what every sample chunk of a real launch repeats
     double untraced_wave = 358.0;  // a tile with sample-independent pixels folds their colour sample by sample
 };
+// What the waves of a REAL launch cost, from the counts its recording launch kept (the launch-shape record): fitted per BLOCK —
+// non-negative least squares of every block's recorded wave time against its counts, over the records of configs 3, 4 and 5,
+// config 4's scene at 4K, Scene3 and Scene_indirect (61 bands, 0.4 M blocks; tools/shape_fit.py on the dumps of a development
+// build, profiles/r04/shape_fit.txt) — so that the rule's figures (dearest block over an even share, simulated fill) come out as
+// they did from round 3's wave TIMES, within 10 %, and its thresholds carry over.  In units in which a pool step weighs what
+// probe_step_weight() says.  Not the balance probe's weights: those are fitted on band totals of a 32-sample probe of a quarter of
+// the pixels (where a group of exact tests stands for everything that grows with the clustered spheres) and stay as they are.
+struct RecordWeights {
+    double group, node_test, mesh_phase, wave;
+};
+constexpr RecordWeights k_record_weights_analytic{110.0, 0.0, 0.0, 2500.0};
+constexpr RecordWeights k_record_weights_mesh{127.0, 34.0, 33.0, 6900.0};  // node_test: a child-box test per lane and round, carrying its round's share of pops, shuffles and pushes
+
 static double probe_step_weight(const srt::KernelParams& K, const ProbeWeights& w) {
     return w.step + w.step_ugroup * ((K.nu + 3) / 4) + w.step_cluster * K.nc + w.step_box * K.nb + (K.n_tris > 0 ? w.step_mesh : 0.0);
 }
@@ -639,8 +652,9 @@ static int consume_record(srt_context* ctx) {
     // the launch-shape record: behind the times, the loop counts of every wave (present when the recording launch kept them)
     ctx->work_sum = 0.0, ctx->work_max = 0.0, ctx->work.clear();
     if (ctx->rec_has_work) {
-        const ProbeWeights pw;
-        const double w[srt::TALLY_N] = {ctx->rec_step_w, pw.group, pw.node_round, pw.leaf_trip, pw.mesh_phase, pw.wave, pw.untraced_wave, 0.0};
+        const RecordWeights& rw = ctx->mesh_image.n_tris > 0 ? k_record_weights_mesh : k_record_weights_analytic;
+        // (order of srt::TALLY_*: steps, groups, node rounds, leaf trips, mesh phases, waves, untraced waves, node tests)
+        const double w[srt::TALLY_N] = {ctx->rec_step_w, rw.group, 0.0, 0.0, rw.mesh_phase, rw.wave, 0.0, rw.node_test};
         const uint32_t* cnt = ctx->h_wg_cost + n;
         ctx->work.resize(n);
         for (size_t i = 0; i < n; ++i) {
@@ -815,6 +829,9 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             const double slots = (double)ctx->cu_count * (K.n_tris > 0 ? 3.0 : 4.0);
             const double ratio = (double)ctx->work_max * slots / ctx->work_sum;
             c = ratio < 0.85 ? (K.n_tris > 0 ? 1 : 2) : (long long)ceil(ratio * 100.0 / (double)dev_switches().chunk_beta);
+            // (mesh bands that are clearly uneven — through the ball's edge — do better with a finer cut, round 4's sweeps of
+            // config 5's bands: rows 1350-1620, ratio 1.5: 155.6 ms in 6 layers, 151.2 in 10; 1388-1492, 3.7: 70.4 in 10, 67.7 in 18)
+            if (K.n_tris > 0 && ratio >= 1.2) c = (long long)ceil(ratio / 0.2);
             shape_source = 1;
 #ifdef SRT_DEV
             if (getenv("SRT_DEBUG_CHUNKS")) fprintf(stderr, "chunks: dearest %.0f sum %.0f blocks %lld slots %.0f ratio %.3f -> c %lld\n", ctx->work_max, ctx->work_sum, wg8, slots, ratio, c);

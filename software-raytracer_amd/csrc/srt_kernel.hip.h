@@ -429,6 +429,36 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             part2(k3, p + 3, tb, pb);
         }
     };
+#ifdef SRT_EXP_PART2LOOP
+    // The exact rounds' second half, per LANE instead of per sphere slot: in a round of 64 items every lane looks at another cluster,
+    // so for each of the four sphere slots SOME lane has a candidate and part2 above runs (nearly) four times a round, each time for
+    // a handful of lanes.  Here every lane takes its own candidates one after the other — the loop makes as many trips as the
+    // lane with the most candidates has (one, seldom two: a ray passes within r of few of a cluster's spheres).  The result is
+    // the lexicographic minimum of (distance, list index) whatever the order the candidates are looked at in: same bits.
+    auto test4c = [&](const float4 s0, const float4 s1, const float4 s2, const float4 s3, int p, V3 ro, V3 rd, bool on, float& tb, int& pb) {
+        const Cand k0 = part1(s0, ro, rd, on), k1 = part1(s1, ro, rd, on), k2 = part1(s2, ro, rd, on), k3 = part1(s3, ro, rd, on);
+        unsigned m = (k0.c ? 1u : 0u) | (k1.c ? 2u : 0u) | (k2.c ? 4u : 0u) | (k3.c ? 8u : 0u);
+        while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
+            const bool c = m != 0u;
+            const bool b1 = (m & 1u) == 0u, b2 = (m & 3u) == 0u, b3 = (m & 7u) == 0u;  // the lowest candidate is not slot 0 / not 0..1 / not 0..2
+            const float tc = b3 ? k3.tc : b2 ? k2.tc : b1 ? k1.tc : k0.tc;
+            const float x = b3 ? k3.x : b2 ? k2.x : b1 ? k1.x : k0.x;
+            const int pj = p + (b3 ? 3 : b2 ? 2 : b1 ? 1 : 0);
+            const float t1 = tc - sqrtf(x);  // Object.hpp:131-133 (lanes without a candidate compute on a dead value)
+            const bool tie = c & (t1 == tb) & (pb >= 0);
+            bool win = c & (t1 < tb);
+            if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // rare: only then are the list indices needed
+                const int op = S.order(pj), ob = S.order(tie ? pb : pj);
+                win = win | (tie & (op < ob));
+            }
+            tb = win ? t1 : tb;
+            pb = win ? pj : pb;
+            m &= m - 1u;
+        }
+    };
+#else
+    auto& test4c = test4;
+#endif
     SRT_TICK(2);
     // ---- 1. uniform spheres: broadcast ds_read_b128, 4 per trip
     for (int j = 0; j + 4 <= S.nu; j += 4) {
@@ -513,7 +543,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                     for (int i = 0; i < K4; ++i) {
                         const int p = S.nu4 + (k * K4 + i) * 4;  // per-lane LDS gather
                         const float4 s0 = S.v[p], s1 = S.v[p + 1], s2 = S.v[p + 2], s3 = S.v[p + 3];
-                        test4(s0, s1, s2, s3, p, ro, rd, on, tb, pb);
+                        test4c(s0, s1, s2, s3, p, ro, rd, on, tb, pb);
                     }
                     if (pb >= 0) atomicMin(&S.res[src], hit_key(tb, S.order(pb), pb));
                 }

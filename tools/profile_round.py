@@ -1,23 +1,25 @@
 #!/usr/bin/env python3
-"""Regenerates profiles/<round>/ and profiles/{counters,mesh_counts}.json on the GPU box.
+"""Regenerates profiles/<round>/ and profiles/counters.json on the GPU box.
 
-usage (through gpurun, from the repo root):  python3 tools/profile_round.py r03 [--only c2,c4,...]
+usage (through gpurun, from the repo root):  python3 tools/profile_round.py r04 [--only c2,c4,...]
 
 For every workload below:
-  profiles/<round>/bench_<name>.json         the bench.py line (roofline, roofline_hbm, cpu_baseline where it applies)
+  profiles/<round>/bench_<name>.json         the bench.py line (roofline with its counted work, roofline_hbm, readback, cpu_baseline where it applies)
   profiles/<round>/kernel_stats_<name>.csv   rocprofv3 --kernel-trace --stats of the same bench.py command
-  profiles/counters.json[workload_key]       PMC counters per FULL launch of the workload, one counter group per pass
+  profiles/<round>/kernel_durations_<name>.json   the same trace launch by launch (tools/dispatches.py: timed launches by position)
+  profiles/<round>/pmc_<name>.json           PMC counters per FULL launch of the workload, one counter group per pass
                                              (tools/pmc_collect.py: never together with a trace domain; FETCH_SIZE and
                                              WRITE_SIZE in passes of their own), summed over the launch's kernels
                                              (pathtrace_kernel + fold_kernel for sample-chunked launches); the TIMED launches are
-                                             picked by position (tools/dispatches.py), every fraction is computed with the
-                                             launch time of the pass the counter came from (stored next to it):
-                                             SQ_INSTS_VALU, hbm_bytes_per_launch = FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024
-                                             (gfx950: FETCH_SIZE reports half of a wide streaming read, MI355X_MICROARCH.md)
-  profiles/mesh_counts.json[workload_key]    mesh workloads: BVH node items and triangle tests per path-sample, counted by
-                                             the development library's STATS=1 counters (tests/mesh_stats.py)
-bench.py reads the two json files to fill roofline.traffic / measured_valu_issue_frac / the counted mesh work; the
-final bench lines are therefore written AFTER the counters.
+                                             picked by position, every fraction is computed with the launch time of the pass the
+                                             counter came from (stored next to it)
+  profiles/counters.json[workload_key]       the same, keyed for bench.py: SQ_INSTS_VALU, hbm_bytes_per_launch = FETCH_SIZE x 1024 x 2
+                                             + WRITE_SIZE x 1024 (gfx950: FETCH_SIZE reports half of a wide streaming read, MI355X_MICROARCH.md)
+  profiles/<round>/valu_model.json           per workload: the VALU instructions rocprofv3 counted (SQ_INSTS_VALU per timed launch) next to
+                                             what bench.py's VALU_MODEL makes of the run's own work counts — the check of the model
+                                             behind roofline.frac
+At the end tools/profile_check.py verifies that trace, counter passes and bench line of every workload describe the same launches
+(kernel instantiation, grid, grid layers).  The launch shape is a function of the inputs (round 4), so they must.
 """
 import glob
 import json
@@ -50,8 +52,11 @@ def run(cmd, **kw):
 def main():
     rnd = sys.argv[1]
     only = None
-    if len(sys.argv) > 3 and sys.argv[2] == "--only":
-        only = set(sys.argv[3].split(","))
+    if "--only" in sys.argv:
+        only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
+    # --bench-only: keep the traces and counters of an earlier pass of this round, redo only the committed bench lines,
+    # valu_model.json and the consistency check (after a change that touches bench.py's pricing but no kernel)
+    bench_only = "--bench-only" in sys.argv
     # everything is written twice: into profiles/ (bench.py reads counters.json / mesh_counts.json from there) and into
     # gpurun_out/profiles/ — the only directory a gpurun call brings back; `cp -r gpurun_out/profiles/. profiles/` afterwards
     out = os.path.join(ROOT, "gpurun_out", "profiles", rnd)
@@ -59,9 +64,9 @@ def main():
     os.makedirs(out, exist_ok=True)
     os.makedirs(scratch, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
-    cpath, mpath = os.path.join(ROOT, "profiles", "counters.json"), os.path.join(ROOT, "profiles", "mesh_counts.json")
+    cpath = os.path.join(ROOT, "profiles", "counters.json")
     counters = json.load(open(cpath)) if os.path.exists(cpath) else {}
-    mesh_counts = json.load(open(mpath)) if os.path.exists(mpath) else {}
+    valu_model = {}
     bench = [sys.executable, os.path.join(ROOT, "bench.py")]
     for name, args, mesh in WORKLOADS:
         if only and name not in only:
@@ -75,10 +80,15 @@ def main():
         line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         key = line["config"]["workload_key"]
         print(name, key, "%.4g samples/s" % line["value"], flush=True)
+        if bench_only:
+            for kind in ("kernel_durations_%s.json", "pmc_%s.json", "kernel_stats_%s.csv"):  # (the check below reads them from `out`)
+                src = os.path.join(ROOT, "profiles", rnd, kind % name)
+                if os.path.exists(src) and not os.path.exists(os.path.join(out, kind % name)):
+                    shutil.copy(src, os.path.join(out, kind % name))
         # 2. kernel trace + stats of the same command
         d = os.path.join(scratch, "trace_" + name)
         shutil.rmtree(d, ignore_errors=True)
-        r = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", os.path.join(ROOT, "bench.py")] + args + steps +
+        r = None if bench_only else run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", os.path.join(ROOT, "bench.py")] + args + steps +
                 ["--no-cpu-baseline"], cwd="/tmp", env=env, timeout=900)
         st = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)
         if st:
@@ -96,7 +106,7 @@ def main():
             json.dump(dur, open(os.path.join(out, "kernel_durations_%s.json" % name), "w"), indent=1, sort_keys=True)
         # 3. counters, one group per pass; timed launches by position, every ratio with the duration of its own pass
         pmc_steps = ["--steps", "3", "--warmup", "3"]
-        r = run([sys.executable, os.path.join(ROOT, "tools", "pmc_collect.py"), "profile_%s/pmc_%s" % (rnd, name), "--groups", "hbm_r,hbm_w,sq1,sq2", "--"] +
+        r = None if bench_only else run([sys.executable, os.path.join(ROOT, "tools", "pmc_collect.py"), "profile_%s/pmc_%s" % (rnd, name), "--groups", "hbm_r,hbm_w,sq1,sq2", "--"] +
                 [a for i, a in enumerate(args) if a not in ("--steps", "--warmup") and (i == 0 or args[i - 1] not in ("--steps", "--warmup"))] + pmc_steps, cwd=ROOT, timeout=2400)
         pj = os.path.join(scratch, "pmc_" + name, "pmc.json")
         if os.path.exists(pj):
@@ -115,39 +125,36 @@ def main():
             json.dump(counters, open(cpath, "w"), indent=1, sort_keys=True)
             json.dump(counters, open(os.path.join(ROOT, "gpurun_out", "profiles", "counters.json"), "w"), indent=1, sort_keys=True)
             open(os.path.join(out, "pmc_%s.json" % name), "w").write(json.dumps(doc, indent=1, sort_keys=True))
-        else:
+        elif not bench_only:
             print(name, "pmc failed:", r.stdout[-300:], r.stderr[-300:])
-        # 4. mesh workloads: counted BVH work per path-sample (STATS=1 development library; per-sample figures do not
-        #    depend on the sample count, so 8 spp of the same frame and bounces are counted)
-        if mesh:
-            cfg = line["config"]
-            m = re.match(r".* (\d+)x(\d+) rows(\d+)-(\d+) spp(\d+) b(\d+)", key)
-            w, h, rb, re_, spp, b = (int(v) for v in m.groups())
-            r = run([sys.executable, os.path.join(ROOT, "tests", "mesh_stats.py"), "--mesh", str(mesh), "--spp", "8", "--bounces", str(b), "--width", str(w),
-                     "--height", str(h), "--rows", "%d,%d" % (rb, re_), "--json"], cwd=ROOT, timeout=600)
-            js = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            if js:
-                ms = json.loads(js[-1])
-                samples = w * (re_ - rb) * 8
-                mesh_counts[key] = {"node_items_per_sample": ms["node items"] / samples, "triangle_tests_per_sample": 4.0 * ms["leaf items"] / samples,  # a leaf item runs four lanes, one triangle slot each
-                                    "mesh_rays_per_sample": ms["go lanes"] / samples, "mesh_phases": ms["mesh phases (waves)"],
-                                    "source": "tests/mesh_stats.py (development library, STATS=1 counters), %dx%d rows %d-%d, 8 spp, %d bounces" % (w, h, rb, re_, b)}
-                json.dump(mesh_counts, open(mpath, "w"), indent=1, sort_keys=True)
-                json.dump(mesh_counts, open(os.path.join(ROOT, "gpurun_out", "profiles", "mesh_counts.json"), "w"), indent=1, sort_keys=True)
-            else:
-                print(name, "mesh_stats failed:", r.stdout[-300:], r.stderr[-300:])
-        # 5. the bench line that is committed (reads the counters written above; with the CPU baseline where it is cheap)
+        # 4. the bench line that is committed (reads the counters written above; with the CPU baseline where it is cheap)
         r = run(bench + args + steps, cwd=ROOT)
         js = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if js:
             open(os.path.join(out, "bench_%s.json" % name), "w").write(js[-1] + "\n")
             d = json.loads(js[-1])
             rf = d["roofline"]
-            print("   -> %.4g samples/s, kernel %.3f ms (cold %.3f), valu frac %.3f (%s), measured issue %s, hbm traffic %s vs algorithmic %d" %
-                  (d["value"] or 0, rf["kernel_ms"], rf["kernel_ms_cold_first_launch"] or 0, rf["frac"], rf["achieved_kind"].split(":")[0],
-                   rf["measured_valu_issue_frac"], rf["traffic"], d["roofline_hbm"]["algorithmic_bytes_per_launch"]), flush=True)
+            print("   -> %.4g samples/s, kernel %.3f ms (cold %.3f), counted valu frac %.3f, measured issue %s, hbm traffic %s vs algorithmic %d, shape %s" %
+                  (d["value"] or 0, rf["kernel_ms"], rf["kernel_ms_cold_first_launch"] or 0, rf["frac"],
+                   rf["measured_valu_issue_frac"], rf["traffic"], d["roofline_hbm"]["algorithmic_bytes_per_launch"], d["config"]["launch_shape"]), flush=True)
+            # the model behind roofline.frac against the instruction counter: executed lane-ops / 64 = wave-level VALU instructions
+            ctr = counters.get(key, {})
+            if ctr.get("SQ_INSTS_VALU") and rf.get("executed_laneops_per_sample"):
+                samples = d["value"] * d["ms_per_step"] * 1e-3
+                modelled = rf["executed_laneops_per_sample"] * samples / 64.0
+                valu_model[name] = {"workload_key": key, "SQ_INSTS_VALU_per_launch": ctr["SQ_INSTS_VALU"], "modelled_valu_instructions_per_launch": modelled,
+                                    "modelled_over_counted": modelled / ctr["SQ_INSTS_VALU"], "pool_steps": rf["counted"]["pool_steps"],
+                                    "valu_model": rf["valu_model"], "counted": rf["counted"],
+                                    "unpriced_instructions_per_step": (ctr["SQ_INSTS_VALU"] - (modelled - (rf["valu_model"]["step"] * rf["counted"]["pool_steps"]))) / rf["counted"]["pool_steps"]}
+                json.dump(valu_model, open(os.path.join(out, "valu_model.json"), "w"), indent=1, sort_keys=True)
+                print("      VALU instructions: counter %.4g, model %.4g (%.3f); what the tests leave per step: %.0f" %
+                      (ctr["SQ_INSTS_VALU"], modelled, modelled / ctr["SQ_INSTS_VALU"], valu_model[name]["unpriced_instructions_per_step"]), flush=True)
         else:
             print(name, "final bench failed:", r.stderr[-500:])
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import profile_check as PC
+    probs = PC.check_round(out)
+    print("profile_check: %s" % ("all workloads describe the same launches" if not probs else "\n  ".join(["PROBLEMS"] + probs)), flush=True)
 
 
 if __name__ == "__main__":
