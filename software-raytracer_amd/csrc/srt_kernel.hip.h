@@ -429,12 +429,13 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             part2(k3, p + 3, tb, pb);
         }
     };
-#ifdef SRT_EXP_PART2LOOP
-    // The exact rounds' second half, per LANE instead of per sphere slot: in a round of 64 items every lane looks at another cluster,
-    // so for each of the four sphere slots SOME lane has a candidate and part2 above runs (nearly) four times a round, each time for
-    // a handful of lanes.  Here every lane takes its own candidates one after the other — the loop makes as many trips as the
-    // lane with the most candidates has (one, seldom two: a ray passes within r of few of a cluster's spheres).  The result is
-    // the lexicographic minimum of (distance, list index) whatever the order the candidates are looked at in: same bits.
+    // The exact rounds' second half, per LANE instead of per sphere slot (round 4): in a round of 64 items every lane looks at another
+    // cluster, so for each of the four sphere slots SOME lane has a candidate and part2 above would run (nearly) four times a round,
+    // each time for a handful of lanes.  Here every lane takes its own candidates one after the other — the loop makes as many trips
+    // as the lane with the most candidates has (one, seldom two: a ray passes within r of few of a cluster's spheres).  The result
+    // is the lexicographic minimum of (distance, list index) whatever the order the candidates are looked at in: same bits.
+    // Interleaved A/B on one box (tests/ab_libs.py, profiles/r04/ab_notes.txt): Scene1 1080p 32 spp 2.265 -> 2.200 ms (-2.9 %),
+    // Scene_indirect -0.7 %, config 3's bands -0.7 %, config 4 -0.5 %, one-sample launches -1 %, Scene3 +0.3 %; 8 scalar registers fewer spilled.
     auto test4c = [&](const float4 s0, const float4 s1, const float4 s2, const float4 s3, int p, V3 ro, V3 rd, bool on, float& tb, int& pb) {
         const Cand k0 = part1(s0, ro, rd, on), k1 = part1(s1, ro, rd, on), k2 = part1(s2, ro, rd, on), k3 = part1(s3, ro, rd, on);
         unsigned m = (k0.c ? 1u : 0u) | (k1.c ? 2u : 0u) | (k2.c ? 4u : 0u) | (k3.c ? 8u : 0u);
@@ -456,9 +457,6 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             m &= m - 1u;
         }
     };
-#else
-    auto& test4c = test4;
-#endif
     SRT_TICK(2);
     // ---- 1. uniform spheres: broadcast ds_read_b128, 4 per trip
     for (int j = 0; j + 4 <= S.nu; j += 4) {
