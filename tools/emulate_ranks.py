@@ -52,7 +52,8 @@ def band_ms(rows):
     return statistics.median(ts[3:])
 
 
-TALLY = ["steps", "groups", "node_rounds", "leaf_trips", "mesh_phases", "waves", "untraced_waves", "_"]  # srt::TALLY_*
+TALLY = ["steps", "groups", "node_rounds", "leaf_trips", "mesh_phases", "waves", "untraced_waves", "node_tests"]  # srt::TALLY_* (the first TALLY_N)
+KEYS = {"group": "groups", "node_round": "node_rounds", "leaf_trip": "leaf_trips", "mesh_phase": "mesh_phases", "wave": "waves", "untraced_wave": "untraced_waves", "node_test": "node_tests"}  # ProbeWeights' names
 probe_rows = consts = None
 if a.weights:
     import ctypes as C
@@ -71,7 +72,7 @@ if a.weights:
     stepw = wt.get("step", 700.0) + wt.get("step_ugroup", 70.0) * consts[0] + wt.get("step_cluster", 12.0) * consts[1] + wt.get("step_box", 45.0) * consts[2] + (wt.get("step_mesh", 60.0) if consts[3] else 0.0)
     row_cost = [0.0] * H
     for j, row in enumerate(probe_rows):
-        c = stepw * row[0] + sum(v * row[TALLY.index(k)] for k, v in wt.items() if k in TALLY)
+        c = stepw * row[0] + sum(v * row[TALLY.index(KEYS.get(k, k))] for k, v in wt.items() if KEYS.get(k, k) in TALLY)
         y0, y1 = 16 * j, min(16 * j + 16, H)
         for y in range(y0, y1):
             row_cost[H - 1 - y] = c / (y1 - y0)
