@@ -10,6 +10,16 @@ import sys
 from conftest import ROOT
 
 
+def test_band_fit_reproduces_round_4s_joint_fit():
+    """tools/band_fit.py on the committed emulations of configs 3 and 5 and Scene3 gives the weights the library ships."""
+    d = os.path.join(ROOT, "profiles", "r04", "band_fit")
+    files = [os.path.join(d, f + ".json") for f in ("c3_w1", "c3_w2", "c5_w1", "c5_w2", "s3_w0", "s3_w1", "s3_w2", "s3_w3")]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "band_fit.py")] + files, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1000:]
+    w = json.loads(re.search(r"^weights: (\{.*\})$", out.stdout, re.M).group(1))
+    assert 100 < w["groups"] < 180 and w["waves"] < 500 and 40 < w["node_tests"] < 90, w
+
+
 def test_band_fit_runs_on_the_committed_iterations():
     files = sorted(os.path.join(ROOT, "profiles", "r03", "band_fit", f) for f in os.listdir(os.path.join(ROOT, "profiles", "r03", "band_fit")))
     files = [f for f in files if int(f.split('iter')[1][0]) <= 4]  # the four joint iterations (5 and 6: config 5 alone, mesh weights only)
@@ -17,17 +27,19 @@ def test_band_fit_runs_on_the_committed_iterations():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "band_fit.py")] + files, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     w = json.loads(re.search(r"weights: (\{.*\})", r.stdout).group(1))
-    assert set(w) == {"groups", "node_rounds", "leaf_trips", "mesh_phases", "waves", "untraced_waves"}
-    assert 300 < w["groups"] < 1500 and 500 < w["leaf_trips"] < 4000 and 2000 < w["waves"] < 12000  # the shipped 660 / 1915 / 5830 lie inside
+    # (round 3's dumps carry seven counts — no child-box tests — and are fitted on configs 3 and 5 alone: the tool still reads them;
+    # the weights the library ships come from round 4's joint fit, test above)
+    assert {"groups", "node_rounds", "leaf_trips", "mesh_phases", "waves", "untraced_waves"} <= set(w) and all(v > 0 for v in w.values())
     assert r.stdout.count("cost/time of the bands") == 24  # 8 files x N = 2, 4, 8
 
 
 def test_probe_weights_in_the_library_match_the_fit_notes():
     src = open(os.path.join(ROOT, "software-raytracer_amd", "csrc", "srt_capi.hip")).read()
-    notes = open(os.path.join(ROOT, "profiles", "r03", "band_fit_fit.txt")).read()
-    for name, key in (("group", "groups"), ("leaf_trip", "leaf_trips"), ("wave", "waves")):
-        v = float(re.search(r"\b%s = ([0-9.]+)" % name, src).group(1))
-        assert '"%s": %d' % (key, round(v)) in notes, (name, v)
+    notes = open(os.path.join(ROOT, "profiles", "r04", "band_fit.txt")).read()
+    fitted = json.loads(re.search(r"^weights: (\{.*\})$", notes, re.M).group(1))
+    for name, key in (("group", "groups"), ("leaf_trip", "leaf_trips"), ("wave", "waves"), ("node_test", "node_tests"), ("untraced_wave", "untraced_waves")):
+        v = float(re.search(r"\b%s = ([0-9.]+)" % name, src[src.index("struct ProbeWeights"):]).group(1))
+        assert abs(v - fitted[key]) <= 0.02 * fitted[key] + 1.0, (name, v, fitted[key])
 
 
 def _write_round(tmp_path, trace_kernels, trace_grids, pass_kernels, pass_grids, layers, frac=0.6, same=True):

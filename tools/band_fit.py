@@ -17,9 +17,9 @@ import sys
 import numpy as np
 from scipy.optimize import least_squares
 
-TALLY = ["steps", "groups", "node_rounds", "leaf_trips", "mesh_phases", "waves", "untraced_waves", "_"]  # srt::TALLY_* (csrc/srt_kernel.hip.h)
-FREE = ["groups", "node_rounds", "leaf_trips", "mesh_phases", "waves", "untraced_waves"]
-PRIOR = dict(groups=138.0, node_rounds=26.0, leaf_trips=776.0, mesh_phases=66.0, waves=3645.0, untraced_waves=360.0)  # a first fit on equal bands
+TALLY = ["steps", "groups", "node_rounds", "leaf_trips", "mesh_phases", "waves", "untraced_waves", "node_tests"]  # srt::TALLY_* (csrc/srt_kernel.hip.h), the first TALLY_N
+FREE = ["groups", "node_rounds", "leaf_trips", "mesh_phases", "waves", "untraced_waves", "node_tests"]
+PRIOR = dict(groups=300.0, node_rounds=26.0, leaf_trips=800.0, mesh_phases=65.0, waves=3000.0, untraced_waves=400.0, node_tests=30.0)  # where the search starts (a weak pull: 0.02)
 STEP = dict(step=700.0, step_ugroup=70.0, step_cluster=12.0, step_box=45.0, step_mesh=60.0)  # read off the ISA, fixed
 
 
@@ -55,6 +55,8 @@ def main(paths):
             if s["split"] != "probe":
                 continue
             C = np.array([band_counts(d, *b) for b in s["bands"]])
+            if C.shape[1] < len(TALLY):  # (round 3's dumps: seven counts and a spare word)
+                C = np.pad(C, ((0, 0), (0, len(TALLY) - C.shape[1])))
             groups.append((f, s["ranks"], C, np.array(s["kernel_ms"]), sw))
 
     def cost(C, sw, wv):
@@ -69,7 +71,7 @@ def main(paths):
         for _, N, C, y, sw in groups:
             l = np.log(cost(C, sw, wv)) - np.log(y)
             r.append((l - l.mean()) * (1.0 if N > 2 else 0.5))
-        return np.concatenate(r + [0.05 * (p - np.log([PRIOR[k] for k in free]))])  # weak pull towards the first fit
+        return np.concatenate(r + [0.02 * (p - np.log([PRIOR[k] for k in free]))])  # weak pull towards the start
 
     sol = least_squares(resid, np.log([PRIOR[k] for k in free]), loss="soft_l1", f_scale=0.05)
     wv = np.exp(sol.x)
@@ -77,7 +79,8 @@ def main(paths):
     for f, N, C, y, sw in groups:
         l = np.log(cost(C, sw, wv)) - np.log(y)
         l -= l.mean()
-        print("%s N=%d: cost/time of the bands against the group's mean, %%: %s" % (f.split("/")[-1], N, " ".join("%+.1f" % (v * 100) for v in l)))
+        print("%s N=%d: cost/time of the bands against the group's mean, %%: %s   -> a split by this cost: mean / slowest about %.3f" %
+              (f.split("/")[-1], N, " ".join("%+.1f" % (v * 100) for v in l), float(np.exp(l.min()))))
 
 
 if __name__ == "__main__":
