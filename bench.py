@@ -51,17 +51,19 @@ SEED, FOV = 0, 55
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 128 * 2.4e9      # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz, no FMA credit
 BAND_ALIGN = 2                             # rows: boundaries of the cost-balanced split (8 cost 2-3 points of balance at N = 8)
-NODE_OPS, TRI_OPS = 240, 40                # lane-ops per BVH node item (8 child boxes) / triangle test
 # What a counted unit of executed work costs in fp32 VALU lane-operations (= instructions x lanes; an FMA is ONE issue slot, like
 # every instruction, against a peak without FMA credit).  sphere / box / triangle are SURVEY §8d's constants — and the kernel's own
 # instruction counts for the candidate test of a sphere (24: srt_kernel.hip.h part1) and the slab test; the others are stated here
 # and derived in DESIGN.md §4.7: a cluster-bound test is 14 instructions (three differences, three 3-term FMA chains, the inflated
-# radius, compare, mask), a quantized BVH child box 21 (six byte conversions, six FMAs, max3 / min3, the culling compares), and
+# radius, compare, mask), a quantized BVH child box 21 (six byte conversions, six FMAs, max3 / min3, the culling compares);
 # `step` is everything a pool step runs besides those tests — ray generation (four hash rounds, two normalisations), shading with
-# the environment's powf, the ordered fold, the task hand-out, the compaction and merge around the exact rounds, hit point and
-# normal — per lane and step, calibrated ONCE on config 2 as (SQ_INSTS_VALU - the priced tests) / pool steps from
-# profiles/r04/pmc_c2.json and checked against the counters of the other workloads (profiles/r04/valu_model.json).
-VALU_MODEL = {"sphere": 24, "box": 35, "triangle": 40, "bound": 14, "bvh_child": 21, "step": 760, "step_mesh": 860, "sample": 30}
+# the environment's powf, the ordered fold, the task hand-out, the compaction and merge around the exact rounds, the second halves
+# of the sphere tests, hit point and normal — per lane and step; `bvh_round` / `mesh_phase` what a node round and a traversal
+# phase run besides their child and triangle tests (pops, shuffles, the scan, pushes; the root tests and the winner's fetch).
+# `step` is calibrated ONCE on config 2, `bvh_round` and `mesh_phase` on config 4: (SQ_INSTS_VALU - the priced tests) / the count,
+# from profiles/r04/pmc_c2.json and pmc_c4.json; profiles/r04/valu_model.json checks the model against the instruction counter of
+# every other workload.
+VALU_MODEL = {"sphere": 24, "box": 35, "triangle": 40, "bound": 14, "bvh_child": 21, "step": 1000, "bvh_round": 150, "mesh_phase": 200, "sample": 30}
 
 # BASELINE.json configs, 1-based.  mesh = tessellation of Scene1's big ball (224 -> 99,904 triangles)
 CONFIGS = {
@@ -80,22 +82,23 @@ def algorithmic_bytes(width, rows, n_objects, resume):
     return px * (4 + 16 + (16 if resume else 0)) + n_objects * 64
 
 
-def algorithmic_laneops_per_sample(rbar, n_sph, n_box, node_items=0.0, tri_tests=0.0):
-    """F = R*(24*N_sph + 35*N_box) + 60*R + 30 fp32 lane-ops per path-sample, plus — for
-    mesh scenes — the COUNTED BVH work per sample (node items x 240 + triangle tests x 40)."""
-    return rbar * (24 * n_sph + 35 * n_box) + 60 * rbar + 30 + node_items * NODE_OPS + tri_tests * TRI_OPS
+def algorithmic_laneops_per_sample(rbar, n_sph, n_box, n_tri=0):
+    """F = R*(24*N_sph + 35*N_box + 40*N_tri) + 60*R + 30 fp32 lane-ops per path-sample — the scan of EVERY primitive
+    for every ray (for the 99,904-triangle scenes: what the BVH saves is in this figure too)."""
+    return rbar * (24 * n_sph + 35 * n_box + 40 * n_tri) + 60 * rbar + 30
 
 
 def executed_laneops(wc, samples, mesh):
     """Lane-operations the launch EXECUTED, from its own loop counts (srt_work_counts as a dict) priced with VALU_MODEL:
-    every test count is lane-level and executed (a wave runs a loop trip for all 64 lanes), a pool step costs its fixed part for
-    64 lanes, every path-sample its accumulate / tone-map share.  None when the launch could not count."""
+    every test count is lane-level and executed (a wave runs a loop trip for all 64 lanes), a pool step, a BVH node round and a
+    traversal phase cost their fixed parts for 64 lanes, every path-sample its accumulate / tone-map share.  None when the launch
+    could not count."""
     if not wc or not wc.get("valid"):
         return None
     m = VALU_MODEL
     return (m["sphere"] * (wc["uniform_sphere_tests"] + wc["cluster_sphere_tests"]) + m["box"] * wc["box_tests"] + m["bound"] * wc["cluster_bound_tests"] +
-            m["bvh_child"] * wc["bvh_child_tests"] + m["triangle"] * wc["triangle_tests"] + (m["step_mesh"] if mesh else m["step"]) * 64 * wc["pool_steps"] +
-            m["sample"] * samples)
+            m["bvh_child"] * wc["bvh_child_tests"] + m["triangle"] * wc["triangle_tests"] + m["step"] * 64 * wc["pool_steps"] +
+            m["bvh_round"] * 64 * wc["bvh_node_rounds"] + m["mesh_phase"] * 64 * wc["mesh_phases"] + m["sample"] * samples)
 
 
 def workload_key(scene, mesh, width, height, rows, spp, bounces):
@@ -454,7 +457,13 @@ def main():
         fresh = new_tracer()
         fresh.bind_output(d_framebuffer=frames[1].data_ptr())
         fresh.set_stream(stream.cuda_stream)
-        fresh.render(spp=1, bounces=1, seed=SEED, first_sample=1, reset=True, rows=(0, min(8, H)))  # (code objects are loaded per process, not per context; kept symmetrical with the run's priming launch)
+        # (what a context allocates once, on its first launch of a grid — the cost-record buffers, 1 MB of pinned memory at 1080p,
+        # tens of milliseconds of host time — is initialisation like srt_create: a first pass allocates, then srt_set_scene makes
+        # the context forget everything it has learned about the frame, as after any scene change)
+        fresh.render(spp=4, bounces=1, seed=SEED, first_sample=1, reset=True, rows=(rb, re))
+        fresh.wait()
+        fresh.set_meshes(meshes, n_mesh)
+        fresh.set_scene(objs, n_obj)
         for _ in range(3):
             pt.render(spp=spp, bounces=bounces, seed=SEED, first_sample=1, reset=True, rows=(rb, re))
         f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -478,13 +487,12 @@ def main():
         # sample (mesh scenes: the BVH work as counted) — what a kernel without culling would have had to execute.
         counted_ok = all(p[3] >= 0 for p in per_rank)
         rank_ex = [p[3] if p[3] >= 0 else 0.0 for p in per_rank]
-        bvh_ops = VALU_MODEL["bvh_child"] * wc["bvh_child_tests"] + VALU_MODEL["triangle"] * wc["triangle_tests"] if n_tri else 0.0
         rank_bf = []
         for (k_i, rays_i, samples_i, *_rest) in per_rank:
-            rank_bf.append(algorithmic_laneops_per_sample(rays_i / samples_i, n_sph, n_box) * samples_i)
+            rank_bf.append(algorithmic_laneops_per_sample(rays_i / samples_i, n_sph, n_box, n_tri) * samples_i)
         slowest_ms = max(p[0] for p in per_rank)
         achieved_valu = sum(rank_ex) / (slowest_ms * 1e-3)
-        bruteforce_valu = (sum(rank_bf) + (bvh_ops if world == 1 else 0.0)) / (slowest_ms * 1e-3)
+        bruteforce_valu = sum(rank_bf) / (slowest_ms * 1e-3)
         peak_valu = VALU_PEAK_LANEOPS * len(per_rank)
         abytes = algorithmic_bytes(W, re - rb, n_obj, resume=False)
         abytes += 32 * traced_samples  # sample-chunked launch: + 16 B written and 16 B read per traced sample (the fold's stream)
@@ -568,10 +576,9 @@ def main():
             "algorithmic": {
                 "bruteforce_equivalent_tflops": bruteforce_valu / 1e12,
                 "speedup_vs_bruteforce": bruteforce_valu / achieved_valu if achieved_valu else None,
-                "laneops_per_sample": (sum(rank_bf) + (bvh_ops if world == 1 else 0.0)) / sum(p[2] for p in per_rank),
-                "note": "SURVEY §8d formula F = R(24 N_sph + 35 N_box) + 60 R + 30 with this run's rays per sample%s: what a scan of every primitive for every ray "
-                        "would execute in the same time; NOT a utilisation (it passes the peak where the kernel culls and shares the primary hit among a pixel's samples)" %
-                        (" + the counted BVH work" if n_tri else ""),
+                "laneops_per_sample": sum(rank_bf) / sum(p[2] for p in per_rank),
+                "note": "SURVEY §8d formula F = R(24 N_sph + 35 N_box + 40 N_tri) + 60 R + 30 with this run's rays per sample: what a scan of every primitive for every ray "
+                        "would execute in the same time; NOT a utilisation (it passes the peak where the kernel culls, walks a BVH and shares the primary hit among a pixel's samples)",
             },
             "roofline_hbm": {
                 "bound": "hbm",

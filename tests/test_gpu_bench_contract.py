@@ -34,7 +34,8 @@ def test_single_gpu_line():
     assert 0 < rf["frac"] <= 1.0 and rf["counted"]["valid"] == 1 and rf["counted"]["pool_steps"] > 0
     m, c = rf["valu_model"], rf["counted"]
     ops = (m["sphere"] * (c["uniform_sphere_tests"] + c["cluster_sphere_tests"]) + m["box"] * c["box_tests"] + m["bound"] * c["cluster_bound_tests"] +
-           m["bvh_child"] * c["bvh_child_tests"] + m["triangle"] * c["triangle_tests"] + m["step"] * 64 * c["pool_steps"] + m["sample"] * 480 * 270 * 4)
+           m["bvh_child"] * c["bvh_child_tests"] + m["triangle"] * c["triangle_tests"] + m["step"] * 64 * c["pool_steps"] +
+           m["bvh_round"] * 64 * c["bvh_node_rounds"] + m["mesh_phase"] * 64 * c["mesh_phases"] + m["sample"] * 480 * 270 * 4)
     assert abs(ops / (rf["kernel_ms"] * 1e-3) / 1e12 - rf["achieved"]) / rf["achieved"] < 1e-9
     assert c["closest_hit_calls"] == c["pool_steps"] + c["waves"] and c["uniform_sphere_tests"] == c["closest_hit_calls"] * 3 * 64  # Scene1: 3 uniform spheres
     assert d["algorithmic"]["speedup_vs_bruteforce"] > 0 and "frac" not in d["algorithmic"]
