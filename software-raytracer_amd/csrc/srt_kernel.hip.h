@@ -471,6 +471,29 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
         bool any = k0.c;
         if (rem >= 2) k1 = part1(s1, o, d, active), any |= k1.c;
         if (rem == 3) k2 = part1(s2, o, d, active), any |= k2.c;
+#ifdef SRT_EXP_UNI_LOOP
+        {   // experiment: the second halves per lane, as in the exact rounds (test4c)
+            unsigned m = (k0.c ? 1u : 0u) | ((rem >= 2 && k1.c) ? 2u : 0u) | ((rem == 3 && k2.c) ? 4u : 0u);
+            while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
+                const bool c = m != 0u;
+                const bool b1 = (m & 1u) == 0u, b2 = (m & 3u) == 0u;
+                const float tc = b2 ? k2.tc : b1 ? k1.tc : k0.tc;
+                const float x = b2 ? k2.x : b1 ? k1.x : k0.x;
+                const int pj = j + (b2 ? 2 : b1 ? 1 : 0);
+                const float t1 = tc - sqrtf(x);
+                const bool tie = c & (t1 == best) & (bp >= 0);
+                bool win = c & (t1 < best);
+                if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {
+                    const int op = S.order(pj), ob = S.order(tie ? bp : pj);
+                    win = win | (tie & (op < ob));
+                }
+                best = win ? t1 : best;
+                bp = win ? pj : bp;
+                m &= m - 1u;
+            }
+            any = false;
+        }
+#endif
         if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
             part2(k0, j, best, bp);
             if (rem >= 2) part2(k1, j + 1, best, bp);
