@@ -265,7 +265,8 @@ const char* srt_gather_path(const srt_context* src);
  * units), from a device-side probe: the path-trace kernel's own path pool, run over a quarter of the pixels for the
  * frame's first 32 samples, COUNTING what its loops do (pool steps, exactly tested sphere groups, BVH rounds, per-tile
  * work) instead of writing the frame; the counts are weighed into a cost.  Nothing of the frame is read or written.
- * About 2 % of a 512-spp launch.  Counts, not times: deterministic — every process of a multi-GPU job computes the
+ * Costs the work of 8 sample-frames on this device (32 samples on a quarter of the pixels: 1.6 % of a 512-spp launch of the
+ * frame, a quarter of a 32-spp one) and a host round trip.  Counts, not times: deterministic — every process of a multi-GPU job computes the
  * same numbers, so the ranks can agree on cost-balanced row bands without talking to each other.  The reference's
  * static split into 16 equal column stripes (Raytracer.cpp:330-342) leaves its workers idle behind the slowest one;
  * equal ROW bands are worse (sky rows cost a tenth of floor rows).  Synchronous. */

@@ -554,6 +554,7 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
     K.off_box = SL.off_box;
     K.off_mat = SL.off_mat;
     K.scene_vec4 = SL.total_vec4;
+    for (int i = 0; i < 4; ++i) K.super_bound[i] = SL.super_bound[i];
     K.scene = ctx->d_scene[img];
     K.bvh_nodes = ctx->d_bvh_nodes;
     K.bvh_tris = ctx->d_bvh_tris;
@@ -1243,11 +1244,13 @@ int srt_read_accumulator(srt_context* ctx, float* dst_rgba) {
 }
 
 // The balance probe: the PROBE instantiation of pathtrace_kernel runs the real path pool over the WHOLE frame for the frame's
-// first PROBE_SAMPLES samples — nothing of the frame is read or written — and every wave adds what its loops did (srt::TALLY_*:
-// pool steps, groups of exactly tested spheres, second halves of the sphere test, BVH rounds, folds, traced and untraced pixels)
-// to its 16 x 16 block's counters.  Counts, not times: the same on every GPU and in every run.  A whole frame at 8 samples is
-// 1.6 % of config 3's launch, 0.8 % of config 5's.
+// first PROBE_SAMPLES = 32 samples on ONE of every workgroup's four waves (a quarter of the pixels) — nothing of the frame is read
+// or written — and every wave adds what its loops did (srt::TALLY_*: pool steps, groups of exactly tested spheres, BVH rounds,
+// triangle trips, phases, child-box tests, tiles with and without untraced pixels) to its 16 x 16 block's counters.  Counts, not
+// times: the same on every GPU and in every run.  Cost: the work of 32 x 1/4 = 8 sample-frames on one device — 1.6 % of a 512-spp
+// launch of the frame, 0.8 % of a 1024-spp one, a quarter of a 32-spp one — plus a host round trip (the call is synchronous).
 constexpr int PROBE_SAMPLES = 32;
+static_assert(PROBE_SAMPLES == 32, "ProbeWeights were fitted on probes of 32 samples (shorter pools take 12..37 % more steps per sample, unevenly over a frame): refit them (tools/band_fit.py) when this changes");
 static int run_pool_probe(srt_context* ctx, int max_bounces, uint32_t seed, std::vector<uint32_t>& counts, int& bx, int& by) {
     SRT_HIP(ctx, hipSetDevice(ctx->device));
     const int W = ctx->width, H = ctx->height;

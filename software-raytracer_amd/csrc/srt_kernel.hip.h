@@ -78,6 +78,7 @@ struct KernelParams {
     int32_t nu;  // uniform spheres that are not padding
     int32_t off_bounds, off_box, off_mat;
     int32_t scene_vec4;  // number of float4 in the scene image
+    float super_bound[4];  // (C.xyz, Rg) of a bounding sphere of all clustered spheres, inflated like a cluster bound; Rg < 0: none
     const float4* scene;
     // EXTENSION: triangle meshes (srt_mesh_bvh.h); n_tris == 0 -> none
     const float4* bvh_nodes;
@@ -385,9 +386,8 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
     float best = __builtin_inff();
     int bp = -1;
     // exact sphere test of ray (ro, rd) against four spheres; updates (tb, pb) with the tie rule.
-    // Part 1 (always): the cheap candidate test d2 <= r*r.  Part 2 (sqrt, compare) runs under
-    // ONE wave-uniform branch per group and one more per sphere, so a group nobody can hit
-    // costs a single branch.
+    // Part 1 (always): the cheap candidate test d2 <= r*r.  The second half (sqrt, compare) runs per lane
+    // over the lane's own candidates (`candidates` below): a group nobody can hit costs a single branch.
     struct Cand {
         float tc, x;  // tc and r*r - d2
         bool c;
@@ -401,54 +401,29 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
         float d2 = (ex * ex + ey * ey) + ez * ez;                                   // :125
         return Cand{tc, s.w - d2, on && !(d2 > s.w)};                               // :127
     };
-    auto part2 = [&](const Cand& k, int p, float& tb, int& pb) {
-        if (__builtin_amdgcn_ballot_w64(k.c) != 0ull) {
-            // (the library sqrtf stays here: its short form behind a wave-uniform window test, as in normalized(), saves seven of
-            // twenty instructions but doubles the code of all 43 inlined copies — measured -2 % .. +2 %, no gain; in the three
-            // copies for the uniform spheres alone, which nearly every ray is a candidate of: -0.9 % .. +0.6 %, noise)
-            float t1 = k.tc - sqrtf(k.x);  // :131-133
-            // Raytracer.cpp:130-132; on an exact tie the earlier entry of ObjectsToRender wins.
-            // Branch-free on purpose (see the note in the triangle phase).
-            const bool tie = k.c & (t1 == tb) & (pb >= 0);
-            bool win = k.c & (t1 < tb);
-            if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // rare: only then are the list indices needed (two LDS reads)
-                const int op = S.order(p), ob = S.order(tie ? pb : p);
-                win = win | (tie & (op < ob));
-            }
-            tb = win ? t1 : tb;
-            pb = win ? p : pb;
-        }
-    };
-    auto test4 = [&](const float4 s0, const float4 s1, const float4 s2, const float4 s3, int p, V3 ro, V3 rd, bool on, float& tb,
-                     int& pb) {
-        const Cand k0 = part1(s0, ro, rd, on), k1 = part1(s1, ro, rd, on), k2 = part1(s2, ro, rd, on), k3 = part1(s3, ro, rd, on);
-        if (__builtin_amdgcn_ballot_w64(k0.c | k1.c | k2.c | k3.c) != 0ull) {
-            part2(k0, p, tb, pb);
-            part2(k1, p + 1, tb, pb);
-            part2(k2, p + 2, tb, pb);
-            part2(k3, p + 3, tb, pb);
-        }
-    };
-    // The exact rounds' second half, per LANE instead of per sphere slot (round 4): in a round of 64 items every lane looks at another
-    // cluster, so for each of the four sphere slots SOME lane has a candidate and part2 above would run (nearly) four times a round,
-    // each time for a handful of lanes.  Here every lane takes its own candidates one after the other — the loop makes as many trips
-    // as the lane with the most candidates has (one, seldom two: a ray passes within r of few of a cluster's spheres).  The result
-    // is the lexicographic minimum of (distance, list index) whatever the order the candidates are looked at in: same bits.
-    // Interleaved A/B on one box (tests/ab_libs.py, profiles/r04/ab_notes.txt): Scene1 1080p 32 spp 2.265 -> 2.200 ms (-2.9 %),
-    // Scene_indirect -0.7 %, config 3's bands -0.7 %, config 4 -0.5 %, one-sample launches -1 %, Scene3 +0.3 %; 8 scalar registers fewer spilled.
-    auto test4c = [&](const float4 s0, const float4 s1, const float4 s2, const float4 s3, int p, V3 ro, V3 rd, bool on, float& tb, int& pb) {
-        const Cand k0 = part1(s0, ro, rd, on), k1 = part1(s1, ro, rd, on), k2 = part1(s2, ro, rd, on), k3 = part1(s3, ro, rd, on);
-        unsigned m = (k0.c ? 1u : 0u) | (k1.c ? 2u : 0u) | (k2.c ? 4u : 0u) | (k3.c ? 8u : 0u);
+    // Second half of the sphere test (sqrt, Object.hpp:131-133; the closest test and its tie rule, Raytracer.cpp:130-132) for a
+    // lane's candidates among four spheres p .. p + 3 (bit i of m: sphere p + i is a candidate), PER LANE: every lane walks its own
+    // candidates, lowest first, so the loop makes as many trips as the lane with the most candidates has — one, seldom two.  (Until
+    // round 4 the second half ran once per sphere SLOT with a candidate in any lane: in an exact round every lane looks at another
+    // cluster, so nearly every slot had one somewhere — about 3.3 second halves a round, each for a handful of lanes; and the
+    // uniform spheres ran one per sphere.)  The result is the lexicographic minimum of (distance, list index) in whatever order the
+    // candidates are looked at: same bits.  Interleaved A/B on one box (profiles/r04/ab_notes.txt): exact rounds: Scene1 1080p 32
+    // spp 2.265 -> 2.200 ms, Scene_indirect -0.7 %, config 3's bands -0.7 %, config 4 -0.5 %, Scene3 +0.3 %; uniform spheres on top:
+    // Scene1 -1.9 %, Scene1_reflection -1.8 %, config 3's floor band -3.1 %, config 4 -1.2 %, Scene3 -0.6 %, Scene_indirect +0.4 %.
+    // Branch-free winner update on purpose (see the note in the triangle phase); a library sqrtf (its short form behind a
+    // wave-uniform window test, as in normalized(), doubled the code of the many inlined copies for no gain: round 3).
+    auto candidates = [&](const Cand& k0, const Cand& k1, const Cand& k2, const Cand& k3, unsigned m, int p, float& tb, int& pb) {
         while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
             const bool c = m != 0u;
             const bool b1 = (m & 1u) == 0u, b2 = (m & 3u) == 0u, b3 = (m & 7u) == 0u;  // the lowest candidate is not slot 0 / not 0..1 / not 0..2
             const float tc = b3 ? k3.tc : b2 ? k2.tc : b1 ? k1.tc : k0.tc;
             const float x = b3 ? k3.x : b2 ? k2.x : b1 ? k1.x : k0.x;
             const int pj = p + (b3 ? 3 : b2 ? 2 : b1 ? 1 : 0);
-            const float t1 = tc - sqrtf(x);  // Object.hpp:131-133 (lanes without a candidate compute on a dead value)
+            const float t1 = tc - sqrtf(x);  // :131-133 (lanes without a candidate compute on a dead value)
+            // Raytracer.cpp:130-132; on an exact tie the earlier entry of ObjectsToRender wins
             const bool tie = c & (t1 == tb) & (pb >= 0);
             bool win = c & (t1 < tb);
-            if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // rare: only then are the list indices needed
+            if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // rare: only then are the list indices needed (two LDS reads)
                 const int op = S.order(pj), ob = S.order(tie ? pb : pj);
                 win = win | (tie & (op < ob));
             }
@@ -457,48 +432,25 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             m &= m - 1u;
         }
     };
+    auto test4c = [&](const float4 s0, const float4 s1, const float4 s2, const float4 s3, int p, V3 ro, V3 rd, bool on, float& tb, int& pb) {
+        const Cand k0 = part1(s0, ro, rd, on), k1 = part1(s1, ro, rd, on), k2 = part1(s2, ro, rd, on), k3 = part1(s3, ro, rd, on);
+        candidates(k0, k1, k2, k3, (k0.c ? 1u : 0u) | (k1.c ? 2u : 0u) | (k2.c ? 4u : 0u) | (k3.c ? 8u : 0u), p, tb, pb);
+    };
     SRT_TICK(2);
     // ---- 1. uniform spheres: broadcast ds_read_b128, 4 per trip
     for (int j = 0; j + 4 <= S.nu; j += 4) {
         const float4 s0 = S.v[j], s1 = S.v[j + 1], s2 = S.v[j + 2], s3 = S.v[j + 3];
-        test4(s0, s1, s2, s3, j, o, d, active, best, bp);
+        test4c(s0, s1, s2, s3, j, o, d, active, best, bp);
     }
     if (S.nu & 3) {  // the last, partial group without its padding (Scene1 has 3 uniform spheres, Scene3 / Scene_indirect 2)
         const int j = S.nu & ~3, rem = S.nu & 3;
         const float4 s0 = S.v[j], s1 = S.v[j + 1], s2 = S.v[j + 2];
         const Cand k0 = part1(s0, o, d, active);
         Cand k1 = k0, k2 = k0;
-        bool any = k0.c;
-        if (rem >= 2) k1 = part1(s1, o, d, active), any |= k1.c;
-        if (rem == 3) k2 = part1(s2, o, d, active), any |= k2.c;
-#ifdef SRT_EXP_UNI_LOOP
-        {   // experiment: the second halves per lane, as in the exact rounds (test4c)
-            unsigned m = (k0.c ? 1u : 0u) | ((rem >= 2 && k1.c) ? 2u : 0u) | ((rem == 3 && k2.c) ? 4u : 0u);
-            while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
-                const bool c = m != 0u;
-                const bool b1 = (m & 1u) == 0u, b2 = (m & 3u) == 0u;
-                const float tc = b2 ? k2.tc : b1 ? k1.tc : k0.tc;
-                const float x = b2 ? k2.x : b1 ? k1.x : k0.x;
-                const int pj = j + (b2 ? 2 : b1 ? 1 : 0);
-                const float t1 = tc - sqrtf(x);
-                const bool tie = c & (t1 == best) & (bp >= 0);
-                bool win = c & (t1 < best);
-                if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {
-                    const int op = S.order(pj), ob = S.order(tie ? bp : pj);
-                    win = win | (tie & (op < ob));
-                }
-                best = win ? t1 : best;
-                bp = win ? pj : bp;
-                m &= m - 1u;
-            }
-            any = false;
-        }
-#endif
-        if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-            part2(k0, j, best, bp);
-            if (rem >= 2) part2(k1, j + 1, best, bp);
-            if (rem == 3) part2(k2, j + 2, best, bp);
-        }
+        unsigned m = k0.c ? 1u : 0u;
+        if (rem >= 2) k1 = part1(s1, o, d, active), m |= k1.c ? 2u : 0u;
+        if (rem == 3) k2 = part1(s2, o, d, active), m |= k2.c ? 4u : 0u;
+        candidates(k0, k1, k2, k0, m, j, best, bp);
     }
     SRT_TICK(3);
     // ---- 2. clustered spheres
@@ -506,10 +458,25 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
         const float dd = __builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x));
         const bool unit = fabsf(dd - 1.0f) <= 1e-6f;  // false for NaN
         if (__builtin_amdgcn_ballot_w64(active && !unit) == 0ull) {
-            tally.add(TALLY_BOUND_CALLS, 1u);
             const float o1 = (fabsf(o.x) + fabsf(o.y)) + fabsf(o.z);
             unsigned long long mask = 0ull;
+#ifdef SRT_EXP_SUPER
+            // experiment: one bound around ALL clustered spheres first — the same test, the same proof (srt_scene_image.h); when no
+            // ray of the wave passes it, the nc cluster bounds are skipped
+            bool near_any = true;
+            if (S.nc >= 4 && P.super_bound[3] >= 0.0f) {
+                float Lx = P.super_bound[0] - o.x, Ly = P.super_bound[1] - o.y, Lz = P.super_bound[2] - o.z;
+                float LL = __builtin_fmaf(Lz, Lz, __builtin_fmaf(Ly, Ly, Lx * Lx));
+                float sd = __builtin_fmaf(Lz, d.z, __builtin_fmaf(Ly, d.y, Lx * d.x));
+                float Rinf = __builtin_fmaf(8e-6f, o1, P.super_bound[3]);
+                near_any = __builtin_amdgcn_ballot_w64(active && __builtin_fmaf(-sd, sd, LL) <= __builtin_fmaf(4e-6f, LL, Rinf * Rinf)) != 0ull;
+            }
+            if (near_any) tally.add(TALLY_BOUND_CALLS, 1u);
+            for (int k = 0; near_any && k < S.nc; ++k) {
+#else
+            tally.add(TALLY_BOUND_CALLS, 1u);
             for (int k = 0; k < S.nc; ++k) {  // phase 1: conservative cluster bounds, uniform reads
+#endif
                 const float4 b = S.bound(k);
                 float Lx = b.x - o.x, Ly = b.y - o.y, Lz = b.z - o.z;
                 float LL = __builtin_fmaf(Lz, Lz, __builtin_fmaf(Ly, Ly, Lx * Lx));
@@ -580,7 +547,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                     for (int i = 0; i < K4; ++i) {
                         const int p = S.nu4 + (k * K4 + i) * 4;
                         const float4 s0 = S.v[p], s1 = S.v[p + 1], s2 = S.v[p + 2], s3 = S.v[p + 3];
-                        test4(s0, s1, s2, s3, p, o, d, on, best, bp);
+                        test4c(s0, s1, s2, s3, p, o, d, on, best, bp);
                     }
                 }
             }
@@ -588,7 +555,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             tally.add(TALLY_GROUPS, (unsigned)((S.nsT - S.nu4) >> 2));
             for (int j = S.nu4; j < S.nsT; j += 4) {
                 const float4 s0 = S.v[j], s1 = S.v[j + 1], s2 = S.v[j + 2], s3 = S.v[j + 3];
-                test4(s0, s1, s2, s3, j, o, d, active, best, bp);
+                test4c(s0, s1, s2, s3, j, o, d, active, best, bp);
             }
         }
     }
