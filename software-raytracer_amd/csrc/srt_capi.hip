@@ -554,7 +554,6 @@ static int fill_kernel_params(srt_context* ctx, const srt_render_params* p, srt:
     K.off_box = SL.off_box;
     K.off_mat = SL.off_mat;
     K.scene_vec4 = SL.total_vec4;
-    for (int i = 0; i < 4; ++i) K.super_bound[i] = SL.super_bound[i];
     K.scene = ctx->d_scene[img];
     K.bvh_nodes = ctx->d_bvh_nodes;
     K.bvh_tris = ctx->d_bvh_tris;

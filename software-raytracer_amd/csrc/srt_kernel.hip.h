@@ -78,7 +78,6 @@ struct KernelParams {
     int32_t nu;  // uniform spheres that are not padding
     int32_t off_bounds, off_box, off_mat;
     int32_t scene_vec4;  // number of float4 in the scene image
-    float super_bound[4];  // (C.xyz, Rg) of a bounding sphere of all clustered spheres, inflated like a cluster bound; Rg < 0: none
     const float4* scene;
     // EXTENSION: triangle meshes (srt_mesh_bvh.h); n_tris == 0 -> none
     const float4* bvh_nodes;
@@ -460,23 +459,11 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
         if (__builtin_amdgcn_ballot_w64(active && !unit) == 0ull) {
             const float o1 = (fabsf(o.x) + fabsf(o.y)) + fabsf(o.z);
             unsigned long long mask = 0ull;
-#ifdef SRT_EXP_SUPER
-            // experiment: one bound around ALL clustered spheres first — the same test, the same proof (srt_scene_image.h); when no
-            // ray of the wave passes it, the nc cluster bounds are skipped
-            bool near_any = true;
-            if (S.nc >= 4 && P.super_bound[3] >= 0.0f) {
-                float Lx = P.super_bound[0] - o.x, Ly = P.super_bound[1] - o.y, Lz = P.super_bound[2] - o.z;
-                float LL = __builtin_fmaf(Lz, Lz, __builtin_fmaf(Ly, Ly, Lx * Lx));
-                float sd = __builtin_fmaf(Lz, d.z, __builtin_fmaf(Ly, d.y, Lx * d.x));
-                float Rinf = __builtin_fmaf(8e-6f, o1, P.super_bound[3]);
-                near_any = __builtin_amdgcn_ballot_w64(active && __builtin_fmaf(-sd, sd, LL) <= __builtin_fmaf(4e-6f, LL, Rinf * Rinf)) != 0ull;
-            }
-            if (near_any) tally.add(TALLY_BOUND_CALLS, 1u);
-            for (int k = 0; near_any && k < S.nc; ++k) {
-#else
+            // (Tried in round 4 and dropped: ONE bound around all clustered spheres first — the same test, the same proof — so that a wave
+            // none of whose rays passes it skips the nc cluster bounds: Scene3 -1.1 %, config 3's middle band -1.4 %, but Scene1 +1.9 %,
+            // Scene_indirect +2.0 %, config 3's floor band +1.7 %: where the rays are, some lane nearly always points at the grid.)
             tally.add(TALLY_BOUND_CALLS, 1u);
             for (int k = 0; k < S.nc; ++k) {  // phase 1: conservative cluster bounds, uniform reads
-#endif
                 const float4 b = S.bound(k);
                 float Lx = b.x - o.x, Ly = b.y - o.y, Lz = b.z - o.z;
                 float LL = __builtin_fmaf(Lz, Lz, __builtin_fmaf(Ly, Ly, Lx * Lx));

@@ -85,9 +85,6 @@ struct SceneLayout {
     // every box centre and half size is a number of magnitude below SRT_BOX_NO_NAN_BOUND (the kernel's NaN-free slab test relies on
     // it, together with the same bound on the ray's origin: see closest_hit)
     bool boxes_finite = true;
-    // a bounding sphere of ALL clustered spheres, inflated exactly like a cluster's (it IS a cluster as far as the proof above goes:
-    // a set of spheres with R_geo >= |c_j - C| + r_j): a wave none of whose rays passes it skips the cluster bounds altogether
-    float super_bound[4] = {0, 0, 0, -1.0f};
 };
 
 // the four environment rows of the constants block (colours through Color's clamping constructor, Common.hpp:253-262)
@@ -294,36 +291,6 @@ inline SceneLayout build_scene_image(const srt_object* objects, size_t count, bo
         float Rgf = (float)Rg;
         if ((double)Rgf < Rg) Rgf = nextafterf(Rgf, INFINITY);
         img[L.off_bounds + c] = make_float4(Cf[0], Cf[1], Cf[2], Rgf);
-    }
-    if (!small.empty()) {  // the super bound: Badoiu-Clarkson centre over all clustered spheres, radius and inflation as for a cluster
-        double c[3] = {0, 0, 0};
-        for (int i : small)
-            for (int a = 0; a < 3; ++a) c[a] += (double)objects[i].position[a] / (double)small.size();
-        for (int t = 1; t <= 256; ++t) {
-            int far = small[0];
-            double dfar = -1;
-            for (int i : small) {
-                const srt_object& o = objects[i];
-                const double dx = (double)o.position[0] - c[0], dy = (double)o.position[1] - c[1], dz = (double)o.position[2] - c[2];
-                const double dd = sqrt(dx * dx + dy * dy + dz * dz) + fabs((double)o.radius);
-                if (dd > dfar) dfar = dd, far = i;
-            }
-            for (int a = 0; a < 3; ++a) c[a] += ((double)objects[far].position[a] - c[a]) / (double)(t + 1);
-        }
-        float Cf[3];
-        for (int a = 0; a < 3; ++a) Cf[a] = (float)c[a];
-        double Rgeo = 0, cmax = 0;
-        for (int i : small) {
-            const srt_object& o = objects[i];
-            const double dx = (double)o.position[0] - Cf[0], dy = (double)o.position[1] - Cf[1], dz = (double)o.position[2] - Cf[2];
-            Rgeo = std::max(Rgeo, sqrt(dx * dx + dy * dy + dz * dz) + fabs((double)o.radius));
-            cmax = std::max(cmax, fabs((double)o.position[0]) + fabs((double)o.position[1]) + fabs((double)o.position[2]));
-        }
-        const double Rg = Rgeo * (1.0 + 1e-5) + 8e-6 * cmax + 1e-30;
-        float Rgf = (float)Rg;
-        if ((double)Rgf < Rg) Rgf = nextafterf(Rgf, INFINITY);
-        if (std::isfinite(Rgf) && std::isfinite(Cf[0]) && std::isfinite(Cf[1]) && std::isfinite(Cf[2]))
-            L.super_bound[0] = Cf[0], L.super_bound[1] = Cf[1], L.super_bound[2] = Cf[2], L.super_bound[3] = Rgf;
     }
     for (size_t j = 0; j < boxes.size(); ++j) {
         const srt_object& o = objects[boxes[j]];

@@ -66,7 +66,8 @@ def main():
     env = dict(os.environ, TMPDIR="/tmp")
     cpath = os.path.join(ROOT, "profiles", "counters.json")
     counters = json.load(open(cpath)) if os.path.exists(cpath) else {}
-    valu_model = {}
+    vpath = os.path.join(ROOT, "profiles", rnd, "valu_model.json")
+    valu_model = json.load(open(vpath)) if os.path.exists(vpath) else {}  # (a round is profiled in several gpurun calls: keep the others' entries)
     bench = [sys.executable, os.path.join(ROOT, "bench.py")]
     for name, args, mesh in WORKLOADS:
         if only and name not in only:
