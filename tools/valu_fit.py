@@ -32,12 +32,20 @@ step = (rows["c2"]["valu"] - rows["c2"]["tests"]) / rows["c2"]["steps"]
 mesh = [r for r in rows.values() if r["rounds"]]
 bvh_round = mesh_phase = 0.0
 if mesh:
+    from scipy.optimize import nnls
+
     A = np.array([[r["rounds"], r["phases"]] for r in mesh], dtype=float)
     y = np.array([r["valu"] - r["tests"] - step * r["steps"] for r in mesh])
-    sol, *_ = np.linalg.lstsq(A / y[:, None], np.ones(len(mesh)), rcond=None)  # relative residuals
-    bvh_round, mesh_phase = (max(float(v), 0.0) for v in sol)
-print("step = %.0f   bvh_round = %.0f   mesh_phase = %.0f   (wave-level VALU instructions per pool step / node round / traversal phase beyond the priced tests)" % (step, bvh_round, mesh_phase))
+    sol, _ = nnls(A / y[:, None], np.ones(len(mesh)))  # non-negative, relative residuals
+    bvh_round, mesh_phase = (float(v) for v in sol)
+print("best fit: step = %.0f (config 2)   bvh_round = %.0f   mesh_phase = %.0f   (wave-level VALU instructions per pool step / node round / traversal phase beyond the priced tests)" % (step, bvh_round, mesh_phase))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+B = bench.VALU_MODEL
+print("bench.py ships: step = %d   bvh_round = %d   mesh_phase = %d   (rounded DOWN to what the cheapest workload leaves: the model is a lower bound of the counter everywhere)" % (B["step"], B["bvh_round"], B["mesh_phase"]))
 for n, r in rows.items():
     model = r["tests"] + step * r["steps"] + bvh_round * r["rounds"] + mesh_phase * r["phases"]
-    print("%-20s SQ_INSTS_VALU %.4g  modelled %.4g  modelled/counted %.3f   (priced tests %.0f %% of the counter; left per step %.0f)" %
-          (n, r["valu"], model, model / r["valu"], 100 * r["tests"] / r["valu"], (r["valu"] - r["tests"]) / r["steps"]))
+    shipped = r["tests"] + B["step"] * r["steps"] + B["bvh_round"] * r["rounds"] + B["mesh_phase"] * r["phases"]
+    print("%-20s SQ_INSTS_VALU %.4g  best fit / counter %.3f   shipped model / counter %.3f   (priced tests %.0f %% of the counter; left per step %.0f)" %
+          (n, r["valu"], model / r["valu"], shipped / r["valu"], 100 * r["tests"] / r["valu"], (r["valu"] - r["tests"]) / r["steps"]))
