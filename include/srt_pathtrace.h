@@ -1,7 +1,7 @@
 /*
  * srt_pathtrace.h — C-ABI of the MI355X path-trace library (libsrt_pathtrace.so).
  *
- * This is the drop-in boundary for ONE hot path of JoshuaLim007/Software-Raytracer:
+ * (ABI 6.)  This is the drop-in boundary for ONE hot path of JoshuaLim007/Software-Raytracer:
  * the per-pixel trace / shade / accumulate loop.  The reference has no plugin or
  * FFI interface; the seam this ABI replaces is the tile worker
  *
