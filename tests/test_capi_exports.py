@@ -27,6 +27,14 @@ def test_struct_layouts_match_header(srt):
     # sizes the header implies (all 4-byte fields, no padding)
     assert C.sizeof(srt.Material) == 44 and C.sizeof(srt.Object) == 80
     assert C.sizeof(srt.Environment) == 60 and C.sizeof(srt.Camera) == 52 and C.sizeof(srt.RenderParams) == 40
+    # ABI 6: srt_stats = 2 x u64, a float and four u32 (36 -> 40 with the tail padding of an 8-byte-aligned struct);
+    # srt_work_counts = two u32 and twelve u64
+    assert C.sizeof(srt.capi.Stats) == 40 and C.sizeof(srt.capi.WorkCounts) == 8 + 12 * 8
+    assert srt.capi.Stats.tile_rows.offset == 24 and srt.capi.Stats.shape_source.offset == 32 and srt.capi.WorkCounts.waves.offset == 8
+    hdr = open(os.path.join(ROOT, "include", "srt_pathtrace.h")).read()
+    m = re.search(r"typedef struct srt_work_counts \{(.*?)\} srt_work_counts;", hdr, re.S)
+    fields = re.findall(r"uint(?:32|64)_t (\w+);", m.group(1))
+    assert fields == [n for n, _ in srt.capi.WorkCounts._fields_], fields  # the ctypes mirror lists the header's fields in the header's order
 
 
 def test_host_library_exports(srt):
