@@ -715,7 +715,10 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                         // node rounds get throttled by the leaf queue's room, +7 %.)
                         // Nodes first, until 64 leaves wait.  The two kinds of round are separate branches — each pops, loads and
                         // fetches its rays on its own — so that neither pays for selects between node and triangle data.
-                        const bool node_round = nN > 0 && nL < 64;
+#ifndef SRT_EXP_LEAF_AT
+#define SRT_EXP_LEAF_AT 64
+#endif
+                        const bool node_round = nN > 0 && nL < SRT_EXP_LEAF_AT;
 #ifdef SRT_STATS
                         st_rounds += 1;
 #endif
