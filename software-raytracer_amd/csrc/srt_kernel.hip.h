@@ -715,10 +715,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                         // node rounds get throttled by the leaf queue's room, +7 %.)
                         // Nodes first, until 64 leaves wait.  The two kinds of round are separate branches — each pops, loads and
                         // fetches its rays on its own — so that neither pays for selects between node and triangle data.
-#ifndef SRT_EXP_LEAF_AT
-#define SRT_EXP_LEAF_AT 64
-#endif
-                        const bool node_round = nN > 0 && nL < SRT_EXP_LEAF_AT;
+                        const bool node_round = nN > 0 && nL < 64;
 #ifdef SRT_STATS
                         st_rounds += 1;
 #endif
@@ -788,12 +785,6 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                                 const float hi = fminf(__builtin_fmaf(tf, 1.00001f, 1e-6f), thr2);
                                 return lo <= hi;
                             };
-#ifdef SRT_EXP_NEAR
-                            // experiment: the node's children are sorted along one axis (srt_mesh_bvh.h); a ray that moves towards + on that axis
-                            // meets the low children first.  The far children are pushed first, so the LIFO pops the near ones first.
-                            const unsigned sort_axis = __float_as_uint(h1.w) & 3u;
-                            const bool rev = sort_axis == 0u ? px : sort_axis == 1u ? py : pz;
-#endif
                             unsigned mask = 0u;
                             if (logP == 0) {  // one lane per item: all 8 children
                                 const unsigned nx0 = px ? lox0 : hix0, fx0 = px ? hix0 : lox0, ny0 = py ? loy0 : hiy0, fy0 = py ? hiy0 : loy0, nz0 = pz ? loz0 : hiz0,
@@ -807,11 +798,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                                 }
                             } else {  // 2 / 4 / 8 lanes per item: this lane takes 4 / 2 / 1 consecutive children
                                 const int nb = 8 >> logP;                 // children of this lane
-#ifdef SRT_EXP_NEAR
-                                const int first = (rev ? ((1 << logP) - 1 - sub) : sub) * nb;  // (the item's higher lanes take the NEARER children: pushed last, popped first)
-#else
                                 const int first = sub * nb;                // its first child
-#endif
                                 const bool second = first >= 4;            // which word of the planes
                                 const unsigned sh = (unsigned)(first & 3) * 8u;
                                 const unsigned wlx = (second ? lox1 : lox0) >> sh, wly = (second ? loy1 : loy0) >> sh, wlz = (second ? loz1 : loz0) >> sh;
@@ -844,16 +831,9 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                                     int w = nN + (int)(excl & 0xFFFFu);
                                     while (__builtin_amdgcn_ballot_w64(mi != 0u) != 0ull) {
                                         if (mi != 0u) {
-#ifdef SRT_EXP_NEAR
-                                            const unsigned bit = rev ? (0x80000000u >> __builtin_clz(mi)) : (mi & (0u - mi));  // far child first
-                                            const unsigned below = bit - 1u;
-                                            qn[w++] = tag | (first_inner + (unsigned)__builtin_popcount(innermask & below));
-                                            mi &= ~bit;
-#else
                                             const unsigned below = (mi & (0u - mi)) - 1u;  // mask of the children before the lowest survivor
                                             qn[w++] = tag | (first_inner + (unsigned)__builtin_popcount(innermask & below));
                                             mi &= mi - 1u;
-#endif
                                         }
                                     }
                                     nN += totN;
@@ -863,18 +843,14 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                                     int w = nL + (int)(excl >> 16);  // (over this round's popped items: their reads have long completed)
                                     while (__builtin_amdgcn_ballot_w64(ml != 0u) != 0ull) {
                                         if (ml != 0u) {
-#ifdef SRT_EXP_NEAR
-                                            const unsigned bit = rev ? (0x80000000u >> __builtin_clz(ml)) : (ml & (0u - ml)), below = bit - 1u;
-#else
                                             const unsigned bit = ml & (0u - ml), below = bit - 1u;
-#endif
                                             const unsigned below2 = bit * bit - 1u;  // the count fields (2 bits each) of the children before
                                             const unsigned cf = counts & below2;
                                             const unsigned first = first_tri + (unsigned)__builtin_popcount(leafmask & below) + (unsigned)__builtin_popcount(cf & 0x5555u) +
                                                                    2u * (unsigned)__builtin_popcount(cf & 0xAAAAu);
                                             const unsigned c2 = 2u * (unsigned)__builtin_ctz(bit);
                                             qlt[-(w++)] = tag | (first * 4u + ((counts >> c2) & 3u));
-                                            ml &= ~bit;
+                                            ml &= ml - 1u;
                                         }
                                     }
                                     nL += totL;

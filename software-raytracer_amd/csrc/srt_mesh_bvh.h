@@ -8,7 +8,7 @@
 //            (e2.xyz, bits(list index))               index) — restores the tie rule
 //   nodes: 5 float4 (80 B) per 8-WIDE inner node, child boxes quantized to 8 bits on the node's own box:
 //            (origin.xyz, bits(ex | ey<<8 | ez<<16 | innermask<<24))   cell size per axis = 2^(e-127)
-//            (bits(first inner child), bits(first leaf triangle), bits(leafmask | counts<<8), bits(sort axis of the children))
+//            (bits(first inner child), bits(first leaf triangle), bits(leafmask | counts<<8), 0)
 //            (lo.x[0..3], lo.x[4..7], lo.y[0..3], lo.y[4..7])   one byte per child
 //            (lo.z[0..3], lo.z[4..7], hi.x[0..3], hi.x[4..7])
 //            (hi.y[0..3], hi.y[4..7], hi.z[0..3], hi.z[4..7])
@@ -238,27 +238,8 @@ inline void build_mesh_image(const srt_object* objects, size_t count, const std:
     // collapse used before (keep expanding the child with the largest area) left the 224 x 224 sphere of BASELINE configs
     // 4-5 with 8499 wide nodes of 4.5 children on average, 8 levels deep.
     struct Wide {
-        int child[8];  // binary node indices, sorted along `axis` (round 4)
+        int child[8];  // binary node indices
         int n;
-        int axis = 0;  // the axis along which the children's centroids spread most: child 0 is the lowest there
-    };
-    // Children in order along ONE axis, so that a traversal can tell the near children of a ray from the far ones by the sign of
-    // one direction component (the kernel pushes the far ones first: the near ones are popped — and their triangles tested — first,
-    // and what lies behind a hit is culled by its distance).  Stable: ties keep the tree's left-to-right order.
-    auto sort_children = [&](Wide& w) {
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        auto centre = [&](int c, int ax) { return 0.5 * ((double)nodes[(size_t)w.child[c]].lo[ax] + (double)nodes[(size_t)w.child[c]].hi[ax]); };
-        for (int c = 0; c < w.n; ++c)
-            for (int ax = 0; ax < 3; ++ax) lo[ax] = std::min(lo[ax], centre(c, ax)), hi[ax] = std::max(hi[ax], centre(c, ax));
-        w.axis = 0;
-        for (int ax = 1; ax < 3; ++ax)
-            if (hi[ax] - lo[ax] > hi[w.axis] - lo[w.axis]) w.axis = ax;
-        int idx[8];
-        for (int c = 0; c < w.n; ++c) idx[c] = c;
-        std::stable_sort(idx, idx + w.n, [&](int a, int b) { return centre(a, w.axis) < centre(b, w.axis); });
-        int sorted[8];
-        for (int c = 0; c < w.n; ++c) sorted[c] = w.child[idx[c]];
-        for (int c = 0; c < w.n; ++c) w.child[c] = sorted[c];
     };
     std::vector<Wide> wide;
     auto area_of = [&](int k) {
@@ -334,7 +315,6 @@ inline void build_mesh_image(const srt_object* objects, size_t count, const std:
             const int k = todo[q].first, depth = todo[q].second;
             Wide w;
             children_of(k, w);
-            sort_children(w);
             for (int c = 0; c < w.n; ++c)
                 if (nodes[w.child[c]].b <= 0) {
                     wide_of[w.child[c]] = (int)wide.size();
@@ -416,7 +396,7 @@ inline void build_mesh_image(const srt_object* objects, size_t count, const std:
         };
         float4* nd = &out.nodes[NODE_VEC4 * k];
         nd[0] = make_float4(lo[0], lo[1], lo[2], bits_of((int32_t)(expo[0] | (expo[1] << 8) | (expo[2] << 16) | (innermask << 24))));
-        nd[1] = make_float4(bits_of(first_inner[k]), bits_of(first_tri[k]), bits_of((int32_t)(leafmask | (counts << 8))), bits_of((int32_t)w.axis));
+        nd[1] = make_float4(bits_of(first_inner[k]), bits_of(first_tri[k]), bits_of((int32_t)(leafmask | (counts << 8))), 0.0f);
         nd[2] = make_float4(pack4(0, 0), pack4(0, 4), pack4(1, 0), pack4(1, 4));  // lo.x[0..7], lo.y[0..7]
         nd[3] = make_float4(pack4(2, 0), pack4(2, 4), pack4(3, 0), pack4(3, 4));  // lo.z, hi.x
         nd[4] = make_float4(pack4(4, 0), pack4(4, 4), pack4(5, 0), pack4(5, 4));  // hi.y, hi.z
