@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "srt_kernel.hip.h"
+#include "srt_launch_shape.h"
 #include "srt_scene_image.h"
 #include "srt_mesh_bvh.h"
 #include "srt_pathtrace.h"
@@ -73,12 +74,10 @@ constexpr DevSwitches k_dev_switches{};
 constexpr const DevSwitches& dev_switches() { return k_dev_switches; }
 #endif
 
-// the launch-shape record of one block of tiles: what its four waves' loops did, weighed (ProbeWeights) — `sum` over the waves
-// (the wave slots the block occupies over time), `longest` the heaviest wave (how long the workgroup holds its slot)
-struct BlockWork {
-    float sum, longest;
-};
 constexpr size_t REC_WORDS = 1 + 4 * srt::TALLY_N;  // per block in the cost record: wave time, then TALLY_N counts for each of the four waves
+// srt_launch_shape.h is host-only C++ (unit-tested on the CPU) and repeats the kernel's tile geometry:
+static_assert(srt::SHAPE_TILE_H == srt::TILE_H && srt::SHAPE_WG_W == srt::WG_W && srt::SHAPE_WG_H == srt::WG_H && srt::SHAPE_WG_TILES_Y == srt::WG_TILES_Y &&
+              srt::SHAPE_WAVES_PER_WG == srt::WG_TILES_X * srt::WG_TILES_Y && srt::SHAPE_TALLY_N == srt::TALLY_N, "srt_launch_shape.h and srt_kernel.hip.h disagree");
 
 struct HostCamera {
     srt_camera cam;
@@ -142,10 +141,7 @@ struct srt_context {
     bool order_stale = true;              // scene / camera changed since the costs were recorded
     // the launch-shape record (round 4): every block's WORK as the recording launch counted it — loop trips under the balance
     // probe's weights, not times — so the sample-chunk rule is a deterministic function of scene, camera, band and call history
-    std::vector<BlockWork> work;          // per block of the recorded grid, longest-running first (what the fill simulation walks)
-    double work_sum = 0.0;                // of the record (0: none), its maximum and its grid:
-    double work_max = 0.0;                //   the dearest block: how uneven the blocks are decides the number of sample chunks
-    unsigned cost_gx = 0, cost_gy = 0;
+    srt::WorkRecord work;                 // the launch-shape record of the current band (srt_launch_shape.h)
     int band_y0 = -1, band_rows = -1;     // the row band the order, the recording and the cost figures above belong to
     bool estimate_stale = true;           // the scene changed since the order was last estimated on the device
     bool order_disabled = false;          // buffers for the feedback could not be allocated
@@ -397,7 +393,7 @@ static int set_scene_impl(srt_context* ctx, const srt_object* objects, size_t co
     ctx->scene_set = true;
     ctx->order_stale = true;
     ctx->estimate_stale = true;
-    ctx->work_sum = 0.0, ctx->work.clear();  // the recorded block work describes another scene
+    ctx->work.clear();  // the recorded block work describes another scene
     // ... and so does a cost copy that may still be in flight, and the dispatch order made from the old scene's costs: both are
     // dropped (the stream was synchronised above, so nothing still writes h_wg_cost), the next launch estimates afresh
     ctx->recording = false;
@@ -589,47 +585,12 @@ struct ProbeWeights {
     double wave = 80.0;            // per tile: staging, primary rays, ring — what every sample chunk of a real launch repeats
     double untraced_wave = 74.0;   // a tile with sample-independent pixels folds their colour sample by sample
 };
-// What the waves of a REAL launch cost, from the counts its recording launch kept (the launch-shape record): fitted per BLOCK —
-// non-negative least squares of every block's recorded wave time against its counts, over the records of configs 3, 4 and 5,
-// config 4's scene at 4K, Scene3 and Scene_indirect (61 bands, 0.4 M blocks; tools/shape_fit.py on the dumps of a development
-// build, profiles/r04/shape_fit.txt) — so that the rule's figures (dearest block over an even share, simulated fill) come out as
-// they did from round 3's wave TIMES, within 10 %, and its thresholds carry over.  In units in which a pool step weighs what
-// probe_step_weight() says.  Not the balance probe's weights: those are fitted on band totals of a 32-sample probe of a quarter of
-// the pixels (where a group of exact tests stands for everything that grows with the clustered spheres) and stay as they are.
-struct RecordWeights {
-    double group, node_test, mesh_phase, wave;
-};
-constexpr RecordWeights k_record_weights_analytic{110.0, 0.0, 0.0, 2500.0};
-constexpr RecordWeights k_record_weights_mesh{127.0, 34.0, 33.0, 6900.0};  // node_test: a child-box test per lane and round, carrying its round's share of pops, shuffles and pushes
-
 static double probe_step_weight(const srt::KernelParams& K, const ProbeWeights& w) {
     return w.step + w.step_ugroup * ((K.nu + 3) / 4) + w.step_cluster * K.nc + w.step_box * K.nb + (K.n_tris > 0 ? w.step_mesh : 0.0);
 }
 static double probe_block_cost(const uint32_t* c, const srt::KernelParams& K, const ProbeWeights& w) {
     return probe_step_weight(K, w) * c[srt::TALLY_STEPS] + w.group * c[srt::TALLY_GROUPS] + w.node_round * c[srt::TALLY_NODE_ROUNDS] + w.leaf_trip * c[srt::TALLY_LEAF_TRIPS] +
            w.mesh_phase * c[srt::TALLY_MESH_PHASES] + w.wave * c[srt::TALLY_WAVES] + w.untraced_wave * c[srt::TALLY_UNTRACED_WAVES] + w.node_test * c[srt::TALLY_NODE_TESTS];
-}
-
-// How full a launch of `layers` sample chunks keeps the wave slots of `slots` resident workgroups, from the recorded work alone:
-// the workgroups are started layer by layer, longest block first (the cost order of the real dispatch), each on the slot that
-// frees first; a workgroup holds its slot for its heaviest wave's work / layers, and its four waves occupy their wave slots for
-// their own work / layers; the result is occupied wave-slot time / (wave slots x the time the last workgroup ends).  A
-// deterministic stand-in for what round 3 read off the recorded launch's event time (wave time / launch time x resident waves):
-// that figure moved with the clock and flipped launch shapes near its threshold.
-static double simulate_fill(const std::vector<BlockWork>& by_length, int layers, int slots) {
-    if (by_length.empty() || slots < 1 || layers < 1) return 1.0;
-    std::vector<double> heap((size_t)slots, 0.0);  // min-heap of the slots' finish times
-    auto cmp = [](double a, double b) { return a > b; };
-    double occupied = 0.0, end = 0.0;
-    for (int z = 0; z < layers; ++z)
-        for (const BlockWork& b : by_length) {
-            std::pop_heap(heap.begin(), heap.end(), cmp);
-            heap.back() += (double)b.longest / (double)layers;
-            end = heap.back() > end ? heap.back() : end;
-            std::push_heap(heap.begin(), heap.end(), cmp);
-            occupied += (double)b.sum / (double)layers;
-        }
-    return end > 0.0 ? occupied / (end * (double)slots * (srt::WG_TILES_X * srt::WG_TILES_Y)) : 1.0;
 }
 
 // A recording launch's cost copy has completed: make the dispatch order of the following launches from the blocks' wave TIMES
@@ -655,30 +616,8 @@ static int consume_record(srt_context* ctx) {
     uint32_t lo = 0xFFFFFFFFu, hi = 0;
     for (size_t i = 0; i < n; ++i) lo = ctx->h_wg_cost[i] < lo ? ctx->h_wg_cost[i] : lo, hi = ctx->h_wg_cost[i] > hi ? ctx->h_wg_cost[i] : hi;
     // the launch-shape record: behind the times, the loop counts of every wave (present when the recording launch kept them)
-    ctx->work_sum = 0.0, ctx->work_max = 0.0, ctx->work.clear();
-    if (ctx->rec_has_work) {
-        const RecordWeights& rw = ctx->mesh_image.n_tris > 0 ? k_record_weights_mesh : k_record_weights_analytic;
-        // (order of srt::TALLY_*: steps, groups, node rounds, leaf trips, mesh phases, waves, untraced waves, node tests)
-        const double w[srt::TALLY_N] = {ctx->rec_step_w, rw.group, 0.0, 0.0, rw.mesh_phase, rw.wave, 0.0, rw.node_test};
-        const uint32_t* cnt = ctx->h_wg_cost + n;
-        ctx->work.resize(n);
-        for (size_t i = 0; i < n; ++i) {
-            double sum = 0.0, longest = 0.0;
-            for (int v = 0; v < 4; ++v) {
-                const uint32_t* c = cnt + (i * 4 + (size_t)v) * srt::TALLY_N;
-                double x = 0.0;
-                for (int k = 0; k < srt::TALLY_N; ++k) x += w[k] * (double)c[k];
-                sum += x;
-                longest = x > longest ? x : longest;
-            }
-            ctx->work[i] = BlockWork{(float)sum, (float)longest};
-            ctx->work_sum += sum;
-            ctx->work_max = sum > ctx->work_max ? sum : ctx->work_max;
-        }
-        // (ties in `longest` keep the block order: std::stable_sort, so the record is the same vector in every run)
-        std::stable_sort(ctx->work.begin(), ctx->work.end(), [](const BlockWork& a, const BlockWork& b) { return a.longest > b.longest; });
-        ctx->cost_gx = ctx->rec_gx, ctx->cost_gy = ctx->rec_gy;
-    }
+    ctx->work.clear();
+    if (ctx->rec_has_work) srt::weigh_record(ctx->h_wg_cost + n, n, ctx->rec_gx, ctx->rec_gy, ctx->rec_step_w, ctx->mesh_image.n_tris > 0, ctx->work);
 #ifdef SRT_DEV
     if (getenv("SRT_DEBUG_CHUNKS")) {  // the time-based figures of round 3 next to the counted ones, for calibration
         double tsum = 0.0;
@@ -691,9 +630,9 @@ static int consume_record(srt_context* ctx) {
             (void)hipGetLastError();
         const double slots = (double)ctx->cu_count * (ctx->mesh_image.n_tris > 0 ? 3.0 : 4.0);
         fprintf(stderr, "record: %zu blocks grid %u x %u | TIME dearest %u sum %.0f ratio %.3f fill %.3f (%.3f ms) | WORK dearest %.0f sum %.0f ratio %.3f", n, ctx->rec_gx, ctx->rec_gy,
-                hi, tsum, tsum > 0 ? hi * slots / tsum : 0.0, tfill, ms, ctx->work_max, ctx->work_sum, ctx->work_sum > 0 ? ctx->work_max * slots / ctx->work_sum : 0.0);
+                hi, tsum, tsum > 0 ? hi * slots / tsum : 0.0, tfill, ms, ctx->work.max, ctx->work.sum, ctx->work.sum > 0 ? ctx->work.max * slots / ctx->work.sum : 0.0);
         const int wslots = ctx->cu_count * (ctx->mesh_image.n_tris > 0 ? 4 : 5);
-        for (int c : {1, 2, 3, 4, 6, 8}) fprintf(stderr, " fill(%d)=%.3f", c, simulate_fill(ctx->work, c, wslots));
+        for (int c : {1, 2, 3, 4, 6, 8}) fprintf(stderr, " fill(%d)=%.3f", c, srt::simulate_fill(ctx->work.blocks, c, wslots));
         fprintf(stderr, "\n");
     }
     if (const char* dump = getenv("SRT_DUMP_RECORD")) {  // development aid (tools/shape_fit.py): the raw record, appended as one binary blob
@@ -760,7 +699,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
         if (ctx->recording) (void)hipEventSynchronize(ctx->ev_cost);  // (nothing may still write h_wg_cost when the next record starts)
         ctx->band_y0 = K.y0, ctx->band_rows = K.rows;
         ctx->order_stale = ctx->estimate_stale = true;
-        ctx->work_sum = 0.0, ctx->work.clear();
+        ctx->work.clear();
         ctx->recording = false;
         ctx->order_gx = ctx->order_gy = 0;
     }
@@ -792,99 +731,24 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
         K.flags |= srt::KF_BLOCK_GRID;
     }
     K.bgrid_w = (int32_t)grid_w, K.bgrid_h = (int32_t)grid_h;
-    const int tile_env = dev_switches().tile_h;
-    int tile_h = srt::TILE_H;
-    const long long wg_x = (grid_w + srt::WG_W - 1) / srt::WG_W;
-    const long long want = 15LL * ctx->cu_count;  // ~4 rounds of the 4 workgroups a CU holds; measured on bands of 30..400 rows
-    while (tile_h > 1 && p->sample_count >= 16 && wg_x * ((grid_h + tile_h * srt::WG_TILES_Y - 1) / (tile_h * srt::WG_TILES_Y)) < want) tile_h >>= 1;
-    // a block grid is 1 / steps^2 of the pixel grid: keep at least two workgroups per CU (the waves' run time is latency)
-    while (bgrid && tile_h > 1 && wg_x * ((grid_h + tile_h * srt::WG_TILES_Y - 1) / (tile_h * srt::WG_TILES_Y)) < 2LL * ctx->cu_count) tile_h >>= 1;
-    if (tile_env == 8 || tile_env == 4 || tile_env == 2 || tile_env == 1) tile_h = tile_env;
-    // Sample-chunked launch, for 64 samples per pixel and more: keep the full 8x8 tiles but give every tile
-    // to several workgroups, each tracing one chunk (>= 16) of the samples and storing the colours; a
-    // second, streaming kernel folds them in order (the running mean is order-dependent).  A narrow stripe
-    // of a multi-GPU frame then runs like the full single-GPU frame — many short workgroups — instead of
-    // few long ones whose tail idles the chip: 135 rows x 256 spp 4.9 ms -> 2.2 ms, and still ~10 % on a
-    // full 1080p frame at 256 spp.  Costs 1 KiB of HBM per tile and sample (falls back to small tiles
-    // when that is not available).
-    // Everything this rule reads is a count: the request, the grid, the chip's CU count and — once the band's recording launch has
-    // run — the blocks' recorded WORK (loop trips, not times).  Same inputs and call history, same shape (round 4; round 3 read the
-    // blocks' wave times and the launch's event time, and config 5's rank-4 band flipped between one piece and nine layers).
-    const int defer_env = dev_switches().defer;  // 0: never, n > 0: force n samples per chunk
-    const long long wg_y8 = (K.rows + srt::WG_H - 1) / srt::WG_H, wg8 = wg_x * wg_y8;
-    int chunk = 0, chunks = 1;
-    uint32_t shape_source = 0;  // 0: the static rule (request and grid only), 1: the band's work record
-    // (scenes with meshes from 32 spp: their few, heavy tiles profit earlier — config 4 at 32 spp +20 %)
-    // (progressive blocks, steps > 1, are traced once per block by the multi-sample instantiation: no sample chunks)
-    if (tile_env == 0 && defer_env != 0 && (p->sample_count >= 64 || defer_env > 0 || K.n_tris > 0) && p->sample_count >= 32 && K.steps <= 1) {
-        long long c = (96LL * ctx->cu_count + wg8 - 1) / wg8;  // about 24 k workgroups in flight over the launch
-        // With block works recorded for this grid (the band's recording launch) the number of chunks follows from how
-        // uneven the blocks are: ratio = the dearest block over an even share of the whole launch per
-        // resident workgroup.  Well below 1 the cost order alone fills the chip — no chunks for meshes (every chunk repeats
-        // the primary hits, mesh phases included, and the colours make a round trip through the sample buffer: config 4,
-        // ratio 0.56, 10.4 -> 9.3 ms; config 5's rank-4 band, 0.80, 74 -> 69-72 ms), two for analytic scenes (finer grains
-        // at the tail: -2..-7 %).  From 0.85 on the dearest block is brought down to 0.3 of a share: config 5's rank-5 band
-        // (0.97) 245 ms unchunked, 201 with 4 chunks, 197 with 7; a 540-row band through the mesh ball (1.4-2.0) 15.7 ms
-        // unchunked, 12.1 with two, 10.8 with three, 9.9 with five.
-        // (no record yet: a mesh launch of >= 6000 blocks — a whole 1080p frame — starts unchunked, which is what the record
-        // of such a frame asks for; smaller ones, the bands of a multi-GPU frame, start with the workgroup-count rule above)
-        if (K.n_tris > 0 && wg8 >= 6000) c = 1;
-        const bool have_record = ctx->work_sum > 0.0 && ctx->cost_gx == (unsigned)wg_x && ctx->cost_gy == (unsigned)wg_y8;
-        if (have_record) {
-            const double slots = (double)ctx->cu_count * (K.n_tris > 0 ? 3.0 : 4.0);
-            const double ratio = (double)ctx->work_max * slots / ctx->work_sum;
-            c = ratio < 0.85 ? (K.n_tris > 0 ? 1 : 2) : (long long)ceil(ratio * 100.0 / (double)dev_switches().chunk_beta);
-            // (mesh bands that are clearly uneven — through the ball's edge — do better with a finer cut, round 4's sweeps of
-            // config 5's bands: rows 1350-1620, ratio 1.5: 155.6 ms in 6 layers, 151.2 in 10; 1388-1492, 3.7: 70.4 in 10, 67.7 in 18)
-            if (K.n_tris > 0 && ratio >= 1.2) c = (long long)ceil(ratio / 0.2);
-            shape_source = 1;
+    // Tile height, sample chunks and the taper of the last chunks: srt_launch_shape.h — a pure function of the request, the grid, the
+    // CU count and the band's work record (counts, not times; round 3 read the blocks' wave times and the launch's event time, and
+    // config 5's rank-4 band flipped between one piece and nine layers).  Same inputs and call history, same shape; unit-tested on
+    // the CPU (tests/native/shape_check.cpp).  The one thing outside it: whether the sample buffer can be had.
+    srt::ShapeRequest req;
+    req.grid_w = grid_w, req.grid_h = grid_h, req.rows = K.rows, req.sample_count = p->sample_count, req.steps = K.steps;
+    req.block_grid = bgrid, req.mesh = K.n_tris > 0, req.cu_count = ctx->cu_count;
+    srt::ShapeOverrides ov;
+    ov.tile_h = dev_switches().tile_h, ov.defer = dev_switches().defer, ov.chunk_beta = dev_switches().chunk_beta;
+    ov.no_taper = (dev_switches().kernel_flags & 0x400) != 0, ov.fill_min = SRT_FILL_MIN;
+    srt::LaunchShape shape = srt::plan_launch_shape(req, &ctx->work, ov);
 #ifdef SRT_DEV
-            if (getenv("SRT_DEBUG_CHUNKS")) fprintf(stderr, "chunks: dearest %.0f sum %.0f blocks %lld slots %.0f ratio %.3f -> c %lld\n", ctx->work_max, ctx->work_sum, wg8, slots, ratio, c);
+    if (getenv("SRT_DEBUG_CHUNKS") && shape.source)
+        fprintf(stderr, "chunks: dearest %.0f sum %.0f blocks %lld ratio %.3f fill %.3f -> %d layer(s) of %d\n", ctx->work.max, ctx->work.sum, shape.wg8, shape.ratio, shape.fill, shape.chunks, shape.chunk);
 #endif
-        }
-        // Analytic scenes, round 3 (five resident workgroups per CU, ring of two): at least ten rounds of workgroups, whatever the
-        // record says — a band of evenly dear blocks has a ratio below 1 and got 2..4 chunks, i.e. 3.4 rounds with the last one
-        // 40 % full: Scene3's rows 270-405 at 512 spp 5.8 ms with 4 chunks, 4.9 with 8, 4.35 with 16; Scene_indirect's 135-row
-        // bands 28.4 -> 26.4 ms, its 540-row half 110 -> 106; config 3's 64..144-row bands -2..-7 %.  Chunks of fewer than 24
-        // samples cost more than they balance (every chunk stages the scene and repeats the primary hits).
-        const long long min_chunk = K.n_tris > 0 ? 16 : 24;
-        if (K.n_tris == 0) {
-            const long long c_fill = (10LL * 5 * ctx->cu_count + wg8 - 1) / wg8;
-            if (c < c_fill) c = c_fill;
-        } else {
-            // Mesh launches: four rounds of their four workgroups per CU.  Every chunk repeats the primary rays' mesh phases, so
-            // chunks are dearer than for analytic scenes and the cost order does well on uneven bands (config 5's rows 1080-1350,
-            // 4 rounds in one piece: 48.6 ms, 50.5 with two chunks) — but a narrow band of evenly dear blocks left in one piece is
-            // 1.9 rounds: config 5's floor band 1812-1938 76.9 ms, 74.6 with two chunks, 72.9 with eight.
-            const long long c_fill = (4LL * 4 * ctx->cu_count + wg8 / 2) / wg8;  // (to the nearest: 4080 blocks are four rounds)
-            if (c < c_fill) c = c_fill;
-            // ... and a launch that would leave a good part of the chip's workgroup slots empty is cut into four: the upper 1066 rows
-            // of config 5 (sky, far spheres, mirror balls: half of its blocks cost nothing, the dear ones make 4.5 rounds) filled 0.73
-            // of the slots in one piece, 76.8 ms; 66.5 with three chunks, 64.4 with six.  Its neighbours fill 0.94..0.96 and lose 1..5 %
-            // to any chunking.  Round 3 took the fill from the recorded launch's event time; now it is simulate_fill() over the recorded
-            // works: list scheduling of the launch as planned so far.
-            // (Only where a chunk still has 64 samples and more: config 4's frame, 64 spp, fills 0.8 of the slots in its first launch
-            // too, and in four chunks of 16 samples it ran 8.05 ms instead of 7.17.)
-            if (have_record && c < 4 && p->sample_count >= 256) {
-                const double fill = simulate_fill(ctx->work, (int)c, ctx->cu_count * 4);
-#ifdef SRT_DEV
-                if (getenv("SRT_DEBUG_CHUNKS")) fprintf(stderr, "chunks: simulated fill of %lld layer(s) %.3f (threshold %.2f)\n", c, fill, SRT_FILL_MIN);
-#endif
-                if (fill < SRT_FILL_MIN) c = 4;
-            }
-        }
-        if (c > p->sample_count / min_chunk) c = p->sample_count / min_chunk;
-        // A mesh launch that the rule leaves in ONE piece keeps full 8 x 8 tiles: the small tiles chosen above for launches of few
-        // blocks (tuned in round 1 on analytic scenes at 16..63 spp) cost the mesh kernel more than they balance — config 5's
-        // floor bands of a cost-balanced 8-rank split (1024 spp, 128 / 208 rows): 107 -> 92 ms, 90 -> 78 ms (round 3).
-        if (c < 2 && defer_env <= 0 && K.n_tris > 0 && tile_env == 0) tile_h = srt::TILE_H;
-        if (c >= 2 || defer_env > 0) {
-            chunk = (int)((p->sample_count + c - 1) / c);
-            if (defer_env > 0) chunk = defer_env;
-            chunks = (int)((p->sample_count + chunk - 1) / chunk);
-        }
-    }
-    if (chunks >= 2) {
+    const long long wg_x = shape.wg_x, wg8 = shape.wg8;
+    if (shape.chunks >= 2) {
+        // Costs 1 KiB of HBM per tile and sample; falls back to small tiles when that is not available
         const size_t tiles = (size_t)wg8 * srt::WG_TILES_X * srt::WG_TILES_Y;
         const size_t need = tiles * (size_t)p->sample_count * 64 * sizeof(float4);
         bool ok = need <= ((size_t)96 << 30);  // (a third of the 288 GB; 24 GB until round 3 — the sky half of config 5 at 4K x 1024 spp needs 67)
@@ -906,27 +770,15 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
             if (hipMalloc((void**)&ctx->d_tile_masks, tiles * sizeof(unsigned long long)) == hipSuccess) ctx->tile_masks_capacity = tiles;
             else ok = false, (void)hipGetLastError();
         }
-        if (!ok) chunks = 1, chunk = 0;  // no room for the sample buffer: small tiles instead
+        if (!ok) srt::shape_without_sample_buffer(shape);  // no room for the sample buffer: small tiles instead
     }
-    const bool defer = chunks >= 2;
-    if (defer) tile_h = srt::TILE_H;
+    srt::finish_launch_shape(shape, p->sample_count, ov);
+    const bool defer = shape.chunks >= 2;
+    const int tile_h = shape.tile_h, chunk = shape.chunk, chunks = shape.chunks;
+    const uint32_t shape_source = shape.source;
     K.tile_h = tile_h;
     K.chunk = defer ? chunk : 0;
-    K.chunk_full = chunks;
-    // Taper: the last two chunks of a launch (the last one, when there are only two or three) run as twice as many of half the size.
-    // The grid's last layers are the last workgroups to start, and a launch ends when its last workgroups do — in a band of evenly
-    // dear blocks that tail is one workgroup's run time, an eighth of a 5 ms band.  Config 3's bands of 60..200 rows -2..-8 %, its
-    // 820-row band -2 %, the whole frame -1 %; config 5's chunked bands (mesh) -6..-9 % (tools/chunk_sweep.py with SRT_KFLAGS=1024
-    // switching it off, profiles/r03/ab_notes.txt); three or four tapered chunks: the same as two.
-    {
-        const int taper = chunks >= 4 ? 2 : 1;
-        if (defer && chunk >= 24 && !(dev_switches().kernel_flags & 0x400)) {
-            const int half = chunk >> 1, full = chunks - taper;                            // layers that keep the full size
-            const long long rest = (long long)p->sample_count - (long long)full * chunk;  // samples behind them (the last chunk may be short)
-            K.chunk_full = full;
-            chunks = full + (int)((rest + half - 1) / half);
-        }
-    }
+    K.chunk_full = shape.chunk_full;
     K.sample_rows = ctx->d_samples;
     K.tile_masks = ctx->d_tile_masks;
     dim3 grid((unsigned)wg_x, (unsigned)((grid_h + tile_h * srt::WG_TILES_Y - 1) / (tile_h * srt::WG_TILES_Y)), (unsigned)chunks);

@@ -32,6 +32,14 @@ def test_scene_image_and_bvh_builders(tmp_path):
     assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout[-400:] + r.stderr[-2000:]
 
 
+def test_launch_shape_rule(tmp_path):
+    """csrc/srt_launch_shape.h — tile height, sample chunks, taper, the fill simulation — is a pure function of its inputs (round 4):
+    the shapes BASELINE's configs take on the GPU, reproduced on the CPU under ASan + UBSan."""
+    exe = _build(tmp_path, "shape_check.cpp", ["-I" + os.path.join(ROOT, "software-raytracer_amd", "csrc")])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout[-600:] + r.stderr[-2000:]
+
+
 def test_json_and_scene_code(tmp_path):
     host = os.path.join(ROOT, "software-raytracer_amd", "host")
     exe = _build(tmp_path, "json_check.cpp", ["-I" + host, "-I" + os.path.join(ROOT, "include"), os.path.join(host, "scene.cpp")])
