@@ -1,8 +1,9 @@
-"""The balance probe on a scene it was NOT fitted on (round 4, the verdict's item 5): srt_estimate_row_costs -> a 4-way split of
-Scene3 (boxes, mirror wall, emitters; the weights of ProbeWeights were fitted on Scene1-based configs 3 and 5) at 1080p and 256
-spp; every band rendered by a context of its own, as a rank would.  mean / slowest of the measured kernel times must reach 0.85
-(the committed emulation, profiles/emulated_ranks.json "held out: ...", has the figures for N = 2 / 4 / 8 and three more scenes).
-A timing assertion with a wide margin: equal bands of this frame sit near 0.6."""
+"""The balance probe on scenes it was not tuned on (round 4, the verdict's item 5): srt_estimate_row_costs -> a 4-way split at
+1080p and 256 spp; every band rendered by a context of its own, as a rank would.  mean / slowest of the measured kernel times must
+reach 0.85.  Scene2 is HELD OUT of every fit of the balance weights (emitter box, other materials); Scene3 (boxes, mirror wall) is
+the scene round 3's weights failed on (0.80 at N = 8) and is part of round 4's joint fit.  The committed emulation
+(profiles/emulated_ranks.json) has N = 2 / 4 / 8 at 512 spp for six workloads.  A timing assertion with a wide margin: equal
+bands of these frames sit at 0.5 and 0.69."""
 import importlib
 import statistics
 
@@ -13,10 +14,11 @@ from conftest import scene_path
 pytestmark = pytest.mark.gpu
 
 
-def test_probe_split_balances_a_held_out_scene(srt):
+@pytest.mark.parametrize("name", ["Scene2", "Scene3"])
+def test_probe_split_balances_a_held_out_scene(srt, name):
     stripes = importlib.import_module("software-raytracer_amd.stripes")
     w, h, spp, bounces, n = 1920, 1080, 256, 8, 4
-    scene = srt.host.Scene(scene_path("Scene3"))
+    scene = srt.host.Scene(scene_path(name))
     objs, cnt = scene.objects_copy()
 
     def tracer():
@@ -44,7 +46,7 @@ def test_probe_split_balances_a_held_out_scene(srt):
     eff = sum(ms) / n / max(ms)
     eq = [band_ms(b) for b in stripes.partition_rows(h, n)]
     eff_eq = sum(eq) / n / max(eq)
-    print("Scene3 1080p 256 spp, N = 4: probe split %s ms %s -> mean / slowest %.3f; equal bands %s -> %.3f" %
-          (bands, ["%.2f" % v for v in ms], eff, ["%.2f" % v for v in eq], eff_eq))
+    print("%s 1080p 256 spp, N = 4: probe split %s ms %s -> mean / slowest %.3f; equal bands %s -> %.3f" %
+          (name, bands, ["%.2f" % v for v in ms], eff, ["%.2f" % v for v in eq], eff_eq))
     assert eff >= 0.85, (bands, ms)
     assert max(ms) <= max(eq) * 1.02  # and the balanced split's slowest rank is no slower than the equal split's
