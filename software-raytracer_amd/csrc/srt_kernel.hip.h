@@ -334,11 +334,19 @@ enum {
 template <bool ON>
 struct Tally {
     __device__ __forceinline__ void add(int, unsigned) {}
+    __device__ __forceinline__ unsigned get(int) const { return 0u; }
 };
+// The counters live in ONE vector register: lane i of the wave holds counter i (TALLY_ALL <= 64).  An add is a compare, a select and
+// an add on a wave-uniform amount — three VALU instructions, a handful of adds per pool step — instead of a scalar add on one of
+// twelve scalar registers: the kernels have no scalar register to spare (the first version kept twelve SGPR counters and spilled
+// 13..25 more of them into vector lanes inside the hot loops: the counting instantiation ran 4..5 % behind the plain one).
+// add() must be called with all 64 lanes active (wave-uniform control flow), with a wave-uniform amount.
 template <>
 struct Tally<true> {
-    unsigned c[TALLY_ALL];
-    __device__ __forceinline__ void add(int i, unsigned v) { c[i] += v; }
+    unsigned v = 0u;
+    unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    __device__ __forceinline__ void add(int i, unsigned x) { v += lane == (unsigned)i ? x : 0u; }
+    __device__ __forceinline__ unsigned get(int i) const { return (unsigned)__builtin_amdgcn_readlane((int)v, i); }
 };
 
 struct Hit {
@@ -1675,16 +1683,12 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
     }
 #endif
     if constexpr (PROBE) {
-        if (lane == 0)
-            for (int i = 0; i < TALLY_N; ++i)
-                if (tally.c[i]) atomicAdd(&P.wg_cost[(size_t)block_id * TALLY_N + i], tally.c[i]);
+        if (lane < TALLY_N && tally.v) atomicAdd(&P.wg_cost[(size_t)block_id * TALLY_N + lane], tally.v);  // (lane i holds counter i)
         return;
     }
     // SRT_RENDER_COUNT_WORK: what this wave's loops did, added to the launch's totals (srt_get_work_counts)
     if constexpr (TALLY) {
-        if (P.work_counter && lane == 0)
-            for (int i = 0; i < TALLY_ALL; ++i)
-                if (tally.c[i]) atomicAdd(&P.work_counter[i], (unsigned long long)tally.c[i]);
+        if (P.work_counter && lane < TALLY_ALL && tally.v) atomicAdd(&P.work_counter[lane], (unsigned long long)tally.v);  // (lane i holds counter i)
     }
     if ((P.flags & 2u) || P.wg_cost) {  // SRT_RENDER_COUNT_RAYS / cost feedback for the dispatch order
         unsigned long long tot = rays;
@@ -1701,10 +1705,9 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         // ... and what the wave's loops did, for the launch-shape rule (srt_render): the first TALLY_N counts of every wave of the
         // block (the four waves of a workgroup apart: a workgroup holds its slot until its slowest wave ends; the layers of a
         // sample-chunked launch add up).  Counts, not times: the same in every run.  The host weighs them (ProbeWeights).
-        if constexpr (TALLY) if (P.wg_cost && lane == 0) {
+        if constexpr (TALLY) if (P.wg_cost && lane < TALLY_N && tally.v) {
             uint32_t* rec = P.wg_cost + P.wg_blocks + ((size_t)block_id * (WG_TILES_X * WG_TILES_Y) + wave) * TALLY_N;
-            for (int i = 0; i < TALLY_N; ++i)
-                if (tally.c[i]) atomicAdd(&rec[i], tally.c[i]);
+            atomicAdd(&rec[lane], tally.v);  // (lane i holds counter i)
         }
     }
 }
