@@ -286,6 +286,10 @@ def main():
     kernel_events = []  # (begin, end, gather end) HIP events on the launch stream around every TIMED step's srt_render and its gather
 
     def step(count_rays=False, timed=False, count_work=False):
+        # (N = 1: no per-step events — the one pair around the whole timed region gives the time per step, and every event record is
+        # a marker on the stream the next launch queues behind: three of them per step cost 1.5 % of config 2's step.  N > 1 needs the
+        # split between kernel and gather.)
+        timed = timed and world > 1
         if timed:
             e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             e0.record(stream)
@@ -333,8 +337,8 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    launch_ms_mean = sum(a.elapsed_time(b) for a, b, _ in kernel_events) / len(kernel_events)  # this rank's srt_render launches only
-    gather_ms_mean = sum(b.elapsed_time(c) for _, b, c in kernel_events) / len(kernel_events)  # ... and its gathers (stream time behind the kernel)
+    launch_ms_mean = sum(a.elapsed_time(b) for a, b, _ in kernel_events) / len(kernel_events) if kernel_events else stream_ms  # this rank's srt_render launches only
+    gather_ms_mean = sum(b.elapsed_time(c) for _, b, c in kernel_events) / len(kernel_events) if kernel_events else 0.0  # ... and its gathers (stream time behind the kernel)
     k_ms = stream_ms if world == 1 else launch_ms_mean
     st_timed = pt.stats()  # the shape of the last timed launch
 
