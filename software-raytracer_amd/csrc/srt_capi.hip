@@ -856,7 +856,7 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     // (a correctness fallback): such launches keep the static shape rule and report no work counts.
     // (A recording launch keeps the counts only where the sample-chunk rule could ever read them — launches of the sample counts the
     // rule applies to.  A 32-sample analytic frame, config 2, records its blocks' times with the plain instantiation: the counting
-    // one is 4..5 % slower, bench.py's kernel_ms_counting_launch, and that would be the frame's FIRST launch.)
+    // one is 0..2 % slower, bench.py's kernel_ms_counting_launch, and that would be the frame's FIRST launch.)
     const bool want_work = (p->flags & SRT_RENDER_COUNT_WORK) != 0;
     const bool rule_applies = (p->sample_count >= 64 || K.n_tris > 0) && p->sample_count >= 32 && K.steps <= 1;
     const bool tally = ((record && rule_applies) || want_work) && in_lds;
