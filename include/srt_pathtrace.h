@@ -123,6 +123,9 @@ typedef struct srt_camera {
 #define SRT_RENDER_PREVIEW 4u     /* SIMPLEDRAW == true: the one-ray preview shader (:147-160)
                                      instead of the path-traced branch (:162-185)           */
 #define SRT_RENDER_COUNT_WORK 8u  /* count what the launch's loops execute (srt_get_work_counts); same image, a little slower */
+#define SRT_RENDER_NO_TIMING 16u  /* do not bracket this render's kernels with timing events: srt_stats.kernel_ms reads 0 for
+                                     it.  Two stream markers less per launch (about 1 % of a 2 ms launch) for a caller that
+                                     queues render after render and times them itself, or not at all */
 
 /* One render call = sample_count successive "frames" of the reference's loop over a
  * band of memory rows, all on the device, accumulator kept in registers in between
@@ -152,7 +155,7 @@ typedef struct srt_render_params {
 typedef struct srt_stats {
     uint64_t rays;          /* GetClosestObject calls (primary counted once per sample; steps > 1: per block, as renderArea traces) */
     uint64_t path_samples;  /* W_band * H_band * sample_count of the last render */
-    float kernel_ms;        /* HIP-event time of the last render's kernel(s) on its stream */
+    float kernel_ms;        /* HIP-event time of the last render's kernel(s) on its stream; 0 for a render with SRT_RENDER_NO_TIMING */
     uint32_t sample_chunks; /* 1: one kernel traced and folded every sample; n > 1: the samples of a tile were split
                                over n workgroups (grid layers) that stored the colours, and a second, streaming kernel folded
                                them in order (16 B written + 16 B read per traced sample on top of the 20 B/pixel) */

@@ -15,7 +15,7 @@ _LIB = os.path.join(_PKG, "libsrt_pathtrace.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_OOM = range(6)
 OBJ_NONE, OBJ_SPHERE, OBJ_BOX, OBJ_MESH = 0, 1, 2, 3
-RENDER_RESET, RENDER_COUNT_RAYS, RENDER_PREVIEW, RENDER_COUNT_WORK = 1, 2, 4, 8
+RENDER_RESET, RENDER_COUNT_RAYS, RENDER_PREVIEW, RENDER_COUNT_WORK, RENDER_NO_TIMING = 1, 2, 4, 8, 16
 ABI_VERSION = 6
 
 # every symbol include/srt_pathtrace.h declares (tests check the library exports them all)
@@ -281,10 +281,10 @@ class PathTracer:
 
     # ---- hot path --------------------------------------------------------------------
     def render(self, *, spp=1, bounces=4, seed=0, first_sample=1, reset=True, rows=None, count_rays=False,
-               preview=False, steps=1, stripe_width=0, selected=-1, count_work=False):
+               preview=False, steps=1, stripe_width=0, selected=-1, count_work=False, timing=True):
         rb, re = rows if rows is not None else (0, self.height)
         flags = ((RENDER_RESET if reset else 0) | (RENDER_COUNT_RAYS if count_rays else 0) | (RENDER_PREVIEW if preview else 0) |
-                 (RENDER_COUNT_WORK if count_work else 0))
+                 (RENDER_COUNT_WORK if count_work else 0) | (0 if timing else RENDER_NO_TIMING))
         p = RenderParams(rb, re, first_sample, spp, bounces, seed, flags, steps, stripe_width, selected)
         self._ck(self.L.srt_render(self._h, C.byref(p)))
 

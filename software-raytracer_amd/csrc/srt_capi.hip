@@ -158,6 +158,7 @@ struct srt_context {
     uint32_t pending_chunks = 1;
     bool count_rays = false;
     bool count_work = false, count_work_valid = false;
+    bool pending_timed = true;  // the last render was bracketed by ev_begin / ev_end (not SRT_RENDER_NO_TIMING)
     uint32_t pending_tile_rows = 8, pending_chunk_samples = 0, pending_shape_source = 0;
     srt_work_counts work_counts{};
     int lds_limit_bytes = 64 * 1024;
@@ -624,7 +625,7 @@ static int consume_record(srt_context* ctx) {
         for (size_t i = 0; i < n; ++i) tsum += (double)ctx->h_wg_cost[i];
         float ms = 0.0f;
         double tfill = 0.0;
-        if (hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end) == hipSuccess && ms > 0.0f)
+        if (ctx->pending_timed && hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end) == hipSuccess && ms > 0.0f)
             tfill = tsum * 1e-5 / ((double)ms * ctx->cu_count * (ctx->mesh_image.n_tris > 0 ? 16.0 : 20.0));
         else
             (void)hipGetLastError();
@@ -638,7 +639,7 @@ static int consume_record(srt_context* ctx) {
     if (const char* dump = getenv("SRT_DUMP_RECORD")) {  // development aid (tools/shape_fit.py): the raw record, appended as one binary blob
         if (FILE* f = fopen(dump, "ab")) {
             float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end) != hipSuccess) ms = 0.0f, (void)hipGetLastError();
+            if (!ctx->pending_timed || hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end) != hipSuccess) ms = 0.0f, (void)hipGetLastError();
             uint32_t ms_bits, sw_bits;
             const float sw = (float)ctx->rec_step_w;
             memcpy(&ms_bits, &ms, 4), memcpy(&sw_bits, &sw, 4);
@@ -866,7 +867,8 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
         SRT_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, srt::TALLY_ALL * sizeof(unsigned long long), ctx->stream));
         K.work_counter = ctx->d_work;
     }
-    SRT_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
+    const bool timing = !(p->flags & SRT_RENDER_NO_TIMING);
+    if (timing) SRT_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     // instantiation: mesh or not, scene image in LDS or HBM, full tiles / small tiles (multi-sample
     // hand-out) / sample chunks, with or without the loop counts; variants 1 / 3 are a development aid for in-process A/B
     // timing.  All are bit-identical.
@@ -908,7 +910,8 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
         hipLaunchKernelGGL(srt::fold_kernel, dim3((unsigned)wg8), dim3(256), 0, ctx->stream, K, (int)wg_x);
     }
     SRT_HIP(ctx, hipGetLastError());
-    SRT_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
+    if (timing) SRT_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
+    ctx->pending_timed = timing;
     if (record) {
         SRT_HIP(ctx, hipMemcpyAsync(ctx->h_wg_cost, ctx->d_wg_cost, REC_WORDS * nwg * 4, hipMemcpyDeviceToHost, ctx->stream));
         SRT_HIP(ctx, hipEventRecord(ctx->ev_cost, ctx->stream));
@@ -1024,7 +1027,7 @@ int srt_get_stats(srt_context* ctx, srt_stats* out) {
     SRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->stats_pending) {
         float ms = 0.0f;
-        SRT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+        if (ctx->pending_timed) SRT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
         ctx->stats.kernel_ms = ms;
         ctx->stats.path_samples = ctx->pending_samples;
         ctx->stats.sample_chunks = ctx->pending_chunks;

@@ -134,3 +134,19 @@ def test_scene_in_hbm_cannot_count(srt, oracle):
     c = pt.work_counts().as_dict()
     assert c["valid"] == 0 and c["pool_steps"] == 0 and np.array_equal(fb, pt.framebuffer())
     pt.close()
+
+
+def test_untimed_render_is_the_same_render(srt, oracle):
+    """SRT_RENDER_NO_TIMING leaves the two timing events out of the stream: the same frame, kernel_ms reads 0, everything else of
+    srt_stats (rays, path-samples, the launch shape) is reported as usual."""
+    pt, _, _, keep = _tracer(srt, oracle, "Scene1", 640, 360)
+    pt.render(spp=8, bounces=6, seed=2, count_rays=True)
+    fb, st = pt.framebuffer(), pt.stats()
+    assert st.kernel_ms > 0
+    pt.render(spp=8, bounces=6, seed=2, count_rays=True, timing=False)
+    st2 = pt.stats()
+    assert st2.kernel_ms == 0 and st2.rays == st.rays and st2.path_samples == st.path_samples and st2.tile_rows == st.tile_rows
+    assert np.array_equal(fb, pt.framebuffer())
+    pt.render(spp=8, bounces=6, seed=2)  # ... and the next timed render is timed again
+    assert pt.stats().kernel_ms > 0
+    pt.close()
