@@ -24,7 +24,7 @@ EXPORTS = [
     "srt_set_scene", "srt_set_meshes", "srt_set_environment", "srt_environment_default", "srt_set_camera",
     "srt_set_stream", "srt_bind_output", "srt_device_framebuffer", "srt_device_accumulator",
     "srt_render", "srt_wait", "srt_poll", "srt_get_stats", "srt_get_work_counts", "srt_pick", "srt_read_framebuffer",
-    "srt_read_accumulator", "srt_write_accumulator", "srt_gather_band", "srt_gather_path", "srt_estimate_row_costs",
+    "srt_read_framebuffer_async", "srt_read_accumulator", "srt_write_accumulator", "srt_gather_band", "srt_gather_path", "srt_estimate_row_costs",
     "srt_selftest_arith",
 ]
 
@@ -187,6 +187,7 @@ def open_library(path):
     L.srt_get_work_counts.argtypes = [ctx, C.POINTER(WorkCounts)]
     L.srt_pick.argtypes = [ctx, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.srt_read_framebuffer.argtypes = [ctx, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+    L.srt_read_framebuffer_async.argtypes = [ctx, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
     L.srt_read_accumulator.argtypes = [ctx, C.POINTER(C.c_float)]
     L.srt_write_accumulator.argtypes = [ctx, C.POINTER(C.c_float)]
     L.srt_gather_band.argtypes = [ctx, ctx, C.c_int, C.c_int]
@@ -319,6 +320,12 @@ class PathTracer:
         out = np.empty((re - rb, self.width), dtype=np.uint32)
         self._ck(self.L.srt_read_framebuffer(self._h, out.ctypes.data_as(C.c_void_p), self.width * 4, rb, re))
         return out
+
+    def read_framebuffer_async(self, dst_ptr, rows=None, copy_stream=0):
+        """srt_read_framebuffer_async: memory rows `rows` into host memory at dst_ptr (pinned, tightly packed), enqueued on
+        hipStream_t `copy_stream` (0: the launch stream) behind the renders enqueued so far; returns at once."""
+        rb, re = rows if rows is not None else (0, self.height)
+        self._ck(self.L.srt_read_framebuffer_async(self._h, C.c_void_p(dst_ptr), self.width * 4, rb, re, C.c_void_p(copy_stream or 0)))
 
     def accumulator(self):
         out = np.empty((self.height, self.width, 4), dtype=np.float32)

@@ -145,7 +145,7 @@ struct srt_context {
     int band_y0 = -1, band_rows = -1;     // the row band the order, the recording and the cost figures above belong to
     bool estimate_stale = true;           // the scene changed since the order was last estimated on the device
     bool order_disabled = false;          // buffers for the feedback could not be allocated
-    hipEvent_t ev_cost = nullptr, ev_order = nullptr, ev_gather = nullptr;
+    hipEvent_t ev_cost = nullptr, ev_order = nullptr, ev_gather = nullptr, ev_read = nullptr;
     unsigned long long peer_asked = 0;    // srt_gather_band: destination devices this context has asked hipDeviceCanAccessPeer about (once per pair)
     unsigned long long peer_direct = 0;   // ... and those it may reach directly (peer access enabled)
     char gather_path[160] = "no gather yet";  // which way this context's last srt_gather_band went (srt_gather_path)
@@ -304,6 +304,7 @@ int srt_destroy(srt_context* ctx) {
     if (ctx->ev_cost) (void)hipEventDestroy(ctx->ev_cost);
     if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
     if (ctx->ev_gather) (void)hipEventDestroy(ctx->ev_gather);
+    if (ctx->ev_read) (void)hipEventDestroy(ctx->ev_read);
     if (ctx->d_tile_masks) (void)hipFree(ctx->d_tile_masks);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
@@ -1086,6 +1087,23 @@ int srt_read_framebuffer(srt_context* ctx, void* dst, size_t pitch_bytes, int ro
     SRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SRT_HIP(ctx, hipMemcpy2D(dst, pitch_bytes, (const char*)ctx->d_fb + (size_t)row_begin * rowb, rowb, rowb,
                              (size_t)(row_end - row_begin), hipMemcpyDeviceToHost));
+    return SRT_OK;
+}
+
+int srt_read_framebuffer_async(srt_context* ctx, void* dst, size_t pitch_bytes, int row_begin, int row_end, void* copy_stream) {
+    if (!ctx || !dst) return SRT_ERR_INVALID_ARG;
+    const size_t rowb = (size_t)ctx->width * 4;
+    if (row_begin < 0 || row_end > ctx->height || row_begin >= row_end || pitch_bytes < rowb)
+        return fail(ctx, SRT_ERR_INVALID_ARG, "srt_read_framebuffer_async: bad rows [%d,%d) or pitch %zu", row_begin, row_end, pitch_bytes);
+    SRT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t cs = copy_stream ? (hipStream_t)copy_stream : ctx->stream;
+    if (cs != ctx->stream) {  // the copy starts when the renders enqueued so far have finished, not before
+        if (!ctx->ev_read) SRT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_read, hipEventDisableTiming));
+        SRT_HIP(ctx, hipEventRecord(ctx->ev_read, ctx->stream));
+        SRT_HIP(ctx, hipStreamWaitEvent(cs, ctx->ev_read, 0));
+    }
+    SRT_HIP(ctx, hipMemcpy2DAsync(dst, pitch_bytes, (const char*)ctx->d_fb + (size_t)row_begin * rowb, rowb, rowb, (size_t)(row_end - row_begin),
+                                  hipMemcpyDeviceToHost, cs));
     return SRT_OK;
 }
 

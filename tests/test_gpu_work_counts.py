@@ -150,3 +150,43 @@ def test_untimed_render_is_the_same_render(srt, oracle):
     pt.render(spp=8, bounces=6, seed=2)  # ... and the next timed render is timed again
     assert pt.stats().kernel_ms > 0
     pt.close()
+
+
+def test_asynchronous_read_back_equals_the_synchronous_one(srt, oracle):
+    """srt_read_framebuffer_async on a second stream, behind the render: the same rows as srt_read_framebuffer; with two bound
+    framebuffers in turn the copy of frame k and the render of frame k + 1 do not disturb each other."""
+    import torch
+
+    w, h = 640, 360
+    pt, _, _, keep = _tracer(srt, oracle, "Scene1", w, h)
+    dev = torch.device("cuda", 0)
+    frames = [torch.zeros((h, w), dtype=torch.int32, device=dev) for _ in range(2)]
+    hosts = [torch.zeros((h, w), dtype=torch.int32).pin_memory() for _ in range(2)]
+    copy_stream = torch.cuda.Stream(dev)
+    copied = [torch.cuda.Event() for _ in range(2)]
+    stream = torch.cuda.Stream(dev)
+    pt.set_stream(stream.cuda_stream)
+    for k in range(4):  # frame k (seed k) renders into buffer k & 1 while frame k - 1 is still travelling out of the other one
+        i = k & 1
+        if k >= 2:
+            stream.wait_event(copied[i])  # the copy of frame k - 2 has left this buffer
+        pt.bind_output(d_framebuffer=frames[i].data_ptr())
+        pt.render(spp=3, bounces=5, seed=k)
+        pt.read_framebuffer_async(hosts[i].data_ptr(), copy_stream=copy_stream.cuda_stream)
+        copied[i].record(copy_stream)
+    torch.cuda.synchronize(dev)
+    objs = oracle.load_scene_json_py(scene_path("Scene1"))
+    oarr, n = oracle.make_objects(objs)
+    ref = srt.PathTracer(w, h)
+    ref.set_scene(C.cast(oarr, C.POINTER(srt.Object)), n)
+    ref.set_camera(srt.default_camera())
+    for k in (2, 3):  # the last frame of each buffer
+        ref.render(spp=3, bounces=5, seed=k)
+        assert np.array_equal(hosts[k & 1].numpy().view(np.uint32), ref.framebuffer()), k
+    ref.close()
+    # a band, on the launch stream itself (copy_stream = 0)
+    part = torch.zeros((100, w), dtype=torch.int32).pin_memory()
+    pt.read_framebuffer_async(part.data_ptr(), rows=(50, 150))
+    pt.wait()
+    assert np.array_equal(part.numpy().view(np.uint32), pt.framebuffer(rows=(50, 150)))
+    pt.close()
