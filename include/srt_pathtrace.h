@@ -179,7 +179,7 @@ typedef struct srt_work_counts {
     uint64_t closest_hit_calls;    /* GetClosestObject at wave level: pool steps + the tiles' primary rays */
     uint64_t uniform_sphere_tests; /* Sphere::Raytrace, spheres every ray is tested against            (Object.hpp:104-141) */
     uint64_t cluster_bound_tests;  /* conservative cluster-bound tests (no counterpart in the reference: the culling filter) */
-    uint64_t cluster_sphere_tests; /* Sphere::Raytrace, clustered spheres, in the exact rounds (64 per group of four and round) */
+    uint64_t cluster_sphere_tests; /* Sphere::Raytrace, clustered spheres, in the exact rounds (a round: 64 lanes x 4, 2 or 1 tests) */
     uint64_t cluster_items;        /* (ray, cluster) pairs that passed the bounds: the rounds' useful lanes */
     uint64_t box_tests;            /* Box::Raytrace                                                    (Object.hpp:173-233) */
     uint64_t bvh_child_tests;      /* EXTENSION: quantized child boxes of BVH nodes */

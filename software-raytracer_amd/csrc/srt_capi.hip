@@ -952,10 +952,21 @@ int srt_debug_set_variant(srt_context* ctx, int variant) {
 #ifdef SRT_STATS
 int srt_debug_read_stats(unsigned long long* out8) {
     (void)hipDeviceSynchronize();
+#if SRT_STATS == 7 || SRT_STATS == 8  // per-wave rows, summed here
+    std::vector<unsigned long long> rows(8 * (size_t)srt::SEG_ROWS);
+    hipError_t e = hipMemcpyFromSymbol(rows.data(), HIP_SYMBOL(srt::g_seg), rows.size() * sizeof(unsigned long long));
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    for (size_t r = 0; r < (size_t)srt::SEG_ROWS; ++r)
+        for (int i = 0; i < 8; ++i) out8[i] += rows[8 * r + (size_t)i];
+    std::fill(rows.begin(), rows.end(), 0ull);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(srt::g_seg), rows.data(), rows.size() * sizeof(unsigned long long));
+    return e == hipSuccess ? 0 : 3;
+#else
     hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(srt::g_stats), 8 * sizeof(unsigned long long));
     unsigned long long z[8] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(srt::g_stats), z, sizeof z);
     return e == hipSuccess ? 0 : 3;
+#endif
 }
 #endif
 
@@ -1050,7 +1061,7 @@ int srt_get_stats(srt_context* ctx, srt_stats* out) {
             wc.uniform_sphere_tests = t[srt::TALLY_CALLS] * nu * 64u;
             wc.box_tests = t[srt::TALLY_CALLS] * nb * 64u;
             wc.cluster_bound_tests = t[srt::TALLY_BOUND_CALLS] * nc * 64u;
-            wc.cluster_sphere_tests = t[srt::TALLY_GROUPS] * 4u * 64u;
+            wc.cluster_sphere_tests = t[srt::TALLY_SPHERE_TESTS] * 64u;
             wc.cluster_items = t[srt::TALLY_ITEMS];
             wc.bvh_child_tests = t[srt::TALLY_NODE_TESTS] * 64u;
             wc.triangle_tests = t[srt::TALLY_LEAF_TRIPS] * 64u;

@@ -150,6 +150,22 @@ struct Prof {
 #define SRT_PROF_ARG
 #define SRT_TICK(i) do { } while (0)
 #endif
+#if defined(SRT_STATS) && (SRT_STATS == 7 || SRT_STATS == 8)  // make dev STATS=7 / 8: wave-cycles per segment of a BVH node round / leaf round (tests/mesh_stats.py, SRT_STATS_MODE=7 / 8)
+constexpr int SEG_ROWS = 1 << 16;  // a row of eight sums per wave (by block and wave, modulo): no contended atomics inside the timed code
+__device__ unsigned long long g_seg[8 * SEG_ROWS];
+// everything issued so far has completed (loads, LDS) and `dep` has been computed when the clock is read
+#define SRT_SEG_(i, dep) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" :: "v"(dep) : "memory"); const long long now_ = (long long)__builtin_readcyclecounter(); seg_acc[i] += now_ - seg_t; seg_t = now_; } while (0)
+#if SRT_STATS == 7
+#define SRT_SEG(i, dep) SRT_SEG_(i, dep)
+#define SRT_SEGL(i, dep) do { } while (0)
+#else
+#define SRT_SEG(i, dep) do { } while (0)
+#define SRT_SEGL(i, dep) SRT_SEG_(i, dep)
+#endif
+#else
+#define SRT_SEG(i, dep) do { } while (0)
+#define SRT_SEGL(i, dep) do { } while (0)
+#endif
 #if defined(SRT_STATS) && SRT_STATS == 6  // make dev STATS=6: per-wave clock records for tools/timer_probe.py (the block-cost timer anomaly)
 constexpr int WAVE_LOG_MAX = 1 << 17;
 __device__ unsigned long long g_wave_log[6 * WAVE_LOG_MAX];
@@ -318,7 +334,7 @@ __device__ __forceinline__ V3 ibox_normal(const BoxRay& br, V3 t1) {
 // mesh phase.)
 enum {
     TALLY_STEPS = 0,       // pool steps (one closest_hit call of the whole wave each)
-    TALLY_GROUPS,          // groups of four clustered spheres put through the exact test (a round of 64 items: K / 4)
+    TALLY_GROUPS,          // groups of four clustered spheres put through the exact test (a round of up to 64 items: K / 4, however many lanes share an item)
     TALLY_NODE_ROUNDS,     // mesh traversal: node rounds
     TALLY_LEAF_TRIPS,      // mesh traversal: triangle trips of the leaf rounds (one triangle test per lane each)
     TALLY_MESH_PHASES,     // mesh traversal: phases started
@@ -329,6 +345,7 @@ enum {
     TALLY_CALLS = 8,       // closest_hit calls (pool steps + the primary ray's): every one runs all uniform spheres and all boxes
     TALLY_BOUND_CALLS,     // ... of which went through the cluster bounds (all of them, unless a lane's direction was not unit length)
     TALLY_ITEMS,           // (ray, cluster) pairs that survived the bounds: the USEFUL lanes of the exact rounds
+    TALLY_SPHERE_TESTS,    // candidate tests of clustered spheres per lane (a round: K with one lane per item, K / 2 or K / 4 when two or four lanes share one)
     TALLY_ALL = 12
 };
 template <bool ON>
@@ -513,20 +530,40 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
-                for (int base = 0; base < total; base += 64) {  // rounds of 64 items
-                    const int w = base + lane;
-                    const bool on = w < total;
-                    const unsigned item = on ? S.work[w] : (unsigned)(lane << 8);
+                // A round takes up to 64 items with one lane each — or, when no more than 32 / 16 are left, two / four lanes per item, each
+                // with two / one of a group's four spheres (round 4): the last round of a step is seldom full — Scene1 has 79 items in
+                // the average step, the second round used to run all four candidate tests in 64 lanes for 15 of them.  The merge is an
+                // atomicMin, so it does not matter how many lanes report for a ray.  Same bits; interleaved A/B
+                // (profiles/r04/ab_notes.txt): config 2 2.179 -> 2.121 ms, one-sample launches -1.9 %, config 3's middle band -1.2 %,
+                // Scene_indirect -1.1 %, Scene1_reflection -0.9 %, Scene3 -0.5 %, config 3's floor band +-0, config 4 +0.7 %.
+                for (int base = 0; base < total;) {
+                    const int rem = total - base;
+                    const int logS = rem <= 16 ? 2 : rem <= 32 ? 1 : 0, n = 4 >> logS;  // (wave-uniform)
+                    const int take = rem < (64 >> logS) ? rem : (64 >> logS);
+                    const int slot = lane >> logS, sub = lane & ((1 << logS) - 1);
+                    const bool on = slot < take;
+                    const unsigned item = on ? S.work[base + slot] : (unsigned)(lane << 8);
+                    base += take;
                     const int src = (int)(item >> 8), k = (int)(item & 63u);
                     V3 ro = v3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
                     V3 rd = v3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
                     float tb = __builtin_inff();
                     int pb = -1;
                     tally.add(TALLY_GROUPS, (unsigned)K4);
+                    tally.add(TALLY_SPHERE_TESTS, (unsigned)(K4 * n));
                     for (int i = 0; i < K4; ++i) {
-                        const int p = S.nu4 + (k * K4 + i) * 4;  // per-lane LDS gather
-                        const float4 s0 = S.v[p], s1 = S.v[p + 1], s2 = S.v[p + 2], s3 = S.v[p + 3];
-                        test4c(s0, s1, s2, s3, p, ro, rd, on, tb, pb);
+                        const int p = S.nu4 + (k * K4 + i) * 4 + sub * n;  // per-lane LDS gather
+                        const Cand k0 = part1(S.v[p], ro, rd, on);
+                        Cand k1 = k0, k2 = k0, k3 = k0;
+                        unsigned m = k0.c ? 1u : 0u;
+                        if (n >= 2) {
+                            k1 = part1(S.v[p + 1], ro, rd, on), m |= k1.c ? 2u : 0u;
+                            if (n == 4) {
+                                k2 = part1(S.v[p + 2], ro, rd, on), m |= k2.c ? 4u : 0u;
+                                k3 = part1(S.v[p + 3], ro, rd, on), m |= k3.c ? 8u : 0u;
+                            }
+                        }
+                        candidates(k0, k1, k2, k3, m, p, tb, pb);
                     }
                     if (pb >= 0) atomicMin(&S.res[src], hit_key(tb, S.order(pb), pb));
                 }
@@ -539,6 +576,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                     const int k = on ? __builtin_ctzll(mask) : 0;
                     mask &= mask - 1ull;
                     tally.add(TALLY_GROUPS, (unsigned)K4);
+                    tally.add(TALLY_SPHERE_TESTS, (unsigned)(K4 * 4));
                     for (int i = 0; i < K4; ++i) {
                         const int p = S.nu4 + (k * K4 + i) * 4;
                         const float4 s0 = S.v[p], s1 = S.v[p + 1], s2 = S.v[p + 2], s3 = S.v[p + 3];
@@ -548,6 +586,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             }
         } else {  // some lane's direction is not unit length (degenerate lerp): brute force
             tally.add(TALLY_GROUPS, (unsigned)((S.nsT - S.nu4) >> 2));
+            tally.add(TALLY_SPHERE_TESTS, (unsigned)(S.nsT - S.nu4));
             for (int j = S.nu4; j < S.nsT; j += 4) {
                 const float4 s0 = S.v[j], s1 = S.v[j + 1], s2 = S.v[j + 2], s3 = S.v[j + 3];
                 test4c(s0, s1, s2, s3, j, o, d, active, best, bp);
@@ -695,6 +734,9 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                 S.res[lane] = ((unsigned long long)okey(best) << 32) | 0xFFFFFFFFull;  // no triangle yet
                 int batch = 64;
                 bool strict = false;
+#if defined(SRT_STATS) && (SRT_STATS == 7 || SRT_STATS == 8)
+                long long seg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 #if defined(SRT_STATS) && SRT_STATS == 5  // make dev STATS=5: wave-cycles per mesh phase and per wave life (tests/mesh_stats.py)
                 const long long st_t0 = (long long)__builtin_readcyclecounter();
 #endif
@@ -727,6 +769,9 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
 #ifdef SRT_STATS
                         st_rounds += 1;
 #endif
+#if defined(SRT_STATS) && (SRT_STATS == 7 || SRT_STATS == 8)
+                        long long seg_t = (long long)__builtin_readcyclecounter();
+#endif
                         if (node_round) {
                             tally.add(TALLY_NODE_ROUNDS, 1u);
                             int logP = 3, takeN = 1;
@@ -749,6 +794,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                             const int slotN = lane >> logP, sub = lane & ((1 << logP) - 1);
                             const bool onN = slotN < takeN;
                             const unsigned item = onN ? qn[nN + slotN] : 0u;
+                            SRT_SEG(0, item);  // the pop
                             const int src = (int)(item >> 26), code = (int)(item & 0x3FFFFFFu);
                             // the five rows of the node are requested before the ray is fetched, so that the memory round trip overlaps
                             // the shuffles.  (Every lane loads — idle lanes the root: a load under a lane mask would make the compiler wait
@@ -763,6 +809,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                             // a child is entered only if a triangle inside could still beat the ray's best hit: entry distance
                             // <= (thr + 1e-5) / 0.9999 (written as an upper bound of it), and <= 10001
                             const float thr2 = fminf(__builtin_fmaf(fabsf(thr), 2e-4f, thr + 1e-5f), 10001.0f);
+                            SRT_SEG(1, ((((h0.x + h1.x) + q0.x) + (q1.x + q2.w)) + ((ro.x + ro.y) + ro.z)) + (((rinv.x + rinv.y) + rinv.z) + (rpad + thr2)));  // node rows, ray
                             const unsigned ex = __float_as_uint(h0.w);
                             const unsigned innermask = ex >> 24, lw = __float_as_uint(h1.z), leafmask = lw & 255u, counts = lw >> 8;
                             // plane distance = q * (cell * rinv) + ((origin -/+ pad) - ro) * rinv, one FMA per plane
@@ -823,6 +870,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                                 mask = m4 << first;
                             }
                             if (!onN) mask = 0u;
+                            SRT_SEG(2, mask);  // child tests
                             const unsigned tag = (unsigned)src << 26;
                             // exclusive prefix sums of both survivor counts in ONE wave scan (inner count in the low half, leaf count in
                             // the high half; six DPP adds instead of eight ballot rounds)
@@ -831,6 +879,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                             const unsigned incl = wave_inclusive_scan(both);
                             const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63), excl = incl - both;
                             const int totN = (int)(total & 0xFFFFu), totL = (int)(total >> 16);
+                            SRT_SEG(3, excl + total);  // scan
                             if (nN + totN + nL + totL > MESH_Q) {
                                 overflow = true;
                             } else {
@@ -864,6 +913,10 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                                     nL += totL;
                                 }
                             }
+                            SRT_SEG(4, mi + ml);  // pushes
+#if defined(SRT_STATS) && SRT_STATS == 7
+                            seg_acc[6] += 1;
+#endif
                         }
                         else {
                             // a leaf round spreads a leaf's <= 4 triangles over 4 / 2 / 1 lanes by the number of leaves waiting: up to 16
@@ -882,12 +935,14 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                             const int slotL = lane >> logL, subL = lane & ((1 << logL) - 1);
                             const bool onL = slotL < takeL;
                             const unsigned item = onL ? qlt[-(nL + slotL)] : 0u;
+                            SRT_SEGL(0, item);  // the pop
                             const int src = (int)(item >> 26), code = (int)(item & 0x3FFFFFFu);
                             const int lcnt = (code & 3) + 1;  // leaf items: (first triangle) * 4 + (count - 1)
                             const float4* rowp = P.bvh_tris + 3 * (size_t)((code >> 2) + (subL < lcnt ? subL : 0));  // (idle lanes: triangle 0)
                             float4 a = rowp[0], b = rowp[1], c = rowp[2];
                             const V3 ro = v3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
                             const V3 rd = v3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
+                            SRT_SEGL(1, ((a.x + b.x) + c.x) + (((ro.x + ro.y) + ro.z) + ((rd.x + rd.y) + rd.z)));  // the first trip's rows, the ray
                             for (int j = 0;; ++j) {
                                 const int k = subL + (j << logL);  // this trip's triangle of the leaf
                                 const bool more = j + 1 < trips;   // (wave-uniform)
@@ -914,9 +969,17 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                                 // the merge key is (ordered t || global triangle id): the id order is (list order of the object,
                                 // triangle index), i.e. the tie rule; atomicMin makes the merge order-independent
                                 if (ok) atomicMin(&S.res[src], ((unsigned long long)okey(t) << 32) | (unsigned)__float_as_int(b.w));
+#if defined(SRT_STATS) && SRT_STATS == 8
+                                if (j == 0) SRT_SEGL(2, t);  // the first trip's arithmetic and merge
+#endif
                                 if (!more) break;
                                 a = na, b = nb, c = nc;
                             }
+                            SRT_SEG(5, a.x);  // a whole leaf round
+                            SRT_SEGL(3, a.x);  // the later trips
+#if defined(SRT_STATS) && (SRT_STATS == 7 || SRT_STATS == 8)
+                            seg_acc[7] += 1;
+#endif
                         }
                         __builtin_amdgcn_wave_barrier();
                     }
@@ -934,6 +997,15 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                     if (SRT_STATS == 1 && overflow) SRT_STAT(6, 1);
 #endif
                 }
+#if defined(SRT_STATS) && (SRT_STATS == 7 || SRT_STATS == 8)
+                {
+                    const int lane_ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                    const unsigned row_ = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6);
+                    const long long v_ = lane_ == 0 ? seg_acc[0] : lane_ == 1 ? seg_acc[1] : lane_ == 2 ? seg_acc[2] : lane_ == 3 ? seg_acc[3] : lane_ == 4 ? seg_acc[4] :
+                                         lane_ == 5 ? seg_acc[5] : lane_ == 6 ? seg_acc[6] : seg_acc[7];
+                    if (lane_ < 8) atomicAdd(&g_seg[8u * (row_ & (unsigned)(SEG_ROWS - 1)) + (unsigned)lane_], (unsigned long long)v_);
+                }
+#endif
 #if defined(SRT_STATS) && SRT_STATS == 5
                 SRT_STAT(0, (long long)__builtin_readcyclecounter() - st_t0);
                 SRT_STAT(4, st_rounds);

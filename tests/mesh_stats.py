@@ -38,6 +38,18 @@ if mode == 5:
     print("phases %d, %.1f rounds each, %.0f wave-cycles per phase = %.0f per round | in mesh phases: %.1f %% of all wave-cycles (%.3g of %.3g), kernel %.3f ms" %
           (o[6], o[4] / ph, o[0] / ph, o[0] / max(o[4], 1), 100.0 * o[0] / max(o[7], 1), o[0], o[7], st.kernel_ms))
     sys.exit(0)
+if mode == 7:
+    nr, lr = max(o[6], 1), max(o[7], 1)
+    seg = [o[i] / nr for i in range(5)]
+    print("node rounds %d: wave-cycles per round %.0f = pop %.0f + rows and ray %.0f + child tests %.0f + scan %.0f + pushes %.0f | leaf rounds %d: %.0f each | kernel %.3f ms" %
+          (o[6], sum(seg), seg[0], seg[1], seg[2], seg[3], seg[4], o[7], o[5] / lr, st.kernel_ms))
+    sys.exit(0)
+if mode == 8:
+    lr = max(o[7], 1)
+    seg = [o[i] / lr for i in range(4)]
+    print("leaf rounds %d: wave-cycles per round %.0f = pop %.0f + first rows and ray %.0f + first trip's tests and merge %.0f + later trips %.0f | kernel %.3f ms" %
+          (o[7], sum(seg), seg[0], seg[1], seg[2], seg[3], st.kernel_ms))
+    sys.exit(0)
 if mode == 2:
     print("histogram by rays entering the phase (1-2, 3-8, 9-32, 33-64): phases", o[:4], "rounds", o[4:])
     sys.exit(0)

@@ -78,7 +78,8 @@ def test_counting_changes_nothing_and_counts_are_consistent(srt, oracle, name, m
     n_box = sum(1 for o in objs if o["type"] == oracle.OBJ_BOX)
     assert c1["box_tests"] == c1["closest_hit_calls"] * n_box * 64
     assert c1["uniform_sphere_tests"] % (c1["closest_hit_calls"] * 64) == 0
-    assert c1["cluster_sphere_tests"] % 256 == 0 and c1["cluster_items"] * 4 <= c1["cluster_sphere_tests"] + 0  # K = 4: an item tests one group of four
+    # K = 4: an item is tested against one group of four, by one, two or four lanes (a round runs 4, 2 or 1 candidate tests in all 64 lanes)
+    assert c1["cluster_sphere_tests"] % 64 == 0 and c1["cluster_items"] * 4 <= c1["cluster_sphere_tests"]
     if mesh:
         assert c1["bvh_child_tests"] > 0 and c1["triangle_tests"] > 0 and c1["mesh_phases"] > 0 and c1["bvh_node_rounds"] > 0
     else:
