@@ -267,8 +267,9 @@ struct Lds {
     __device__ __forceinline__ float4 bound(int k) const { return v[off_bounds + k]; }
     __device__ __forceinline__ float4 box_c(int j) const { return v[off_box + 2 * j]; }
     __device__ __forceinline__ float4 box_h(int j) const { return v[off_box + 2 * j + 1]; }
-    __device__ __forceinline__ float4 mat(int p, int row) const { return v[off_mat + 3 * p + row]; }
-    __device__ __forceinline__ int order(int p) const { return __float_as_int(v[off_mat + 3 * p + 2].w); }
+    // (24-bit multiplies: primitive ids are below 2^15; a plain `3 * p` became a quarter-rate 64-bit v_mad_u64_u32 per look-up)
+    __device__ __forceinline__ float4 mat(int p, int row) const { return v[off_mat + __mul24(3, p) + row]; }
+    __device__ __forceinline__ int order(int p) const { return __float_as_int(v[off_mat + __mul24(3, p) + 2].w); }
 };
 
 // sign(float3) component (Common.hpp:328-333): t != 0 ? t / abs(t) : 0.  For finite t != 0 the quotient is exactly +-1, for
@@ -483,12 +484,17 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
         const bool unit = fabsf(dd - 1.0f) <= 1e-6f;  // false for NaN
         if (__builtin_amdgcn_ballot_w64(active && !unit) == 0ull) {
             const float o1 = (fabsf(o.x) + fabsf(o.y)) + fabsf(o.z);
-            unsigned long long mask = 0ull;
+            unsigned mlo = 0u, mhi = 0u;  // this lane's clusters: bit k of (mhi : mlo) = the ray may touch cluster k
             // (Tried in round 4 and dropped: ONE bound around all clustered spheres first — the same test, the same proof — so that a wave
             // none of whose rays passes it skips the nc cluster bounds: Scene3 -1.1 %, config 3's middle band -1.4 %, but Scene1 +1.9 %,
             // Scene_indirect +2.0 %, config 3's floor band +1.7 %: where the rays are, some lane nearly always points at the grid.)
             tally.add(TALLY_BOUND_CALLS, 1u);
-            for (int k = 0; k < S.nc; ++k) {  // phase 1: conservative cluster bounds, uniform reads
+            // The lane's mask is shifted in bit by bit — a select and a share of a shift-or per bound, where `mask |= 1ull << k` cost two
+            // moves of the scalar bit into vector registers, two selects and an or — and turned round once at the end; it stays in two
+            // 32-bit words (the 64-bit find-first-set and clear-lowest of the scatter loop were 12 instructions a trip, now 7; scenes
+            // with more than 32 clusters take a second loop).  Round 4; same bits; interleaved A/B (profiles/r04/ab_notes.txt): config 2
+            // 2.165 -> 2.085 ms, config 3's middle band -2.7 %, one-sample launches -2.3 %, Scene3 -1.8 %, config 4 -1.6 %, the others -0.5 %.
+            auto passes = [&](int k) {
                 const float4 b = S.bound(k);
                 float Lx = b.x - o.x, Ly = b.y - o.y, Lz = b.z - o.z;
                 float LL = __builtin_fmaf(Lz, Lz, __builtin_fmaf(Ly, Ly, Lx * Lx));
@@ -496,12 +502,20 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                 float Rinf = __builtin_fmaf(8e-6f, o1, b.w);
                 float lhs = __builtin_fmaf(-sd, sd, LL);
                 float rhs = __builtin_fmaf(4e-6f, LL, Rinf * Rinf);
-                if (lhs <= rhs) mask |= 1ull << k;
+                return lhs <= rhs ? 1u : 0u;
+            };
+            {
+                const int n_lo = S.nc < 32 ? S.nc : 32;
+                for (int k = 0; k < n_lo; ++k) mlo = (mlo << 1) | passes(k);  // phase 1: conservative cluster bounds, uniform reads
+                mlo = active ? __builtin_bitreverse32(mlo) >> (32 - n_lo) : 0u;  // (nc > 0 here)
+                if (S.nc > 32) {
+                    for (int k = 32; k < S.nc; ++k) mhi = (mhi << 1) | passes(k);
+                    mhi = active ? __builtin_bitreverse32(mhi) >> (64 - S.nc) : 0u;
+                }
             }
-            if (!active) mask = 0ull;
             const int K4 = S.K >> 2;
-            // exclusive prefix sum of popcount(mask) over the wave: one DPP scan (six adds; seven ballot slices before)
-            const int cnt = __builtin_popcountll(mask);
+            // exclusive prefix sum of the lanes' cluster counts over the wave: one DPP scan (six adds; seven ballot slices before)
+            const int cnt = __builtin_popcount(mlo) + __builtin_popcount(mhi);
             const unsigned incl = wave_inclusive_scan((unsigned)cnt);
             const int prefix = (int)incl - cnt;
             const int total = __builtin_amdgcn_readlane((int)incl, 63);
@@ -520,12 +534,21 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                 // the lane's own best so far enters the merge slot
                 S.res[lane] = bp >= 0 ? hit_key(best, S.order(bp), bp) : ~0ull;
                 {  // scatter this lane's (lane, cluster) items behind its prefix
-                    unsigned long long m = mask;
+                    unsigned m = mlo;
                     int w = prefix;
-                    while (__builtin_amdgcn_ballot_w64(m != 0ull) != 0ull) {
-                        if (m != 0ull) {
-                            S.work[w++] = (unsigned short)((lane << 8) | __builtin_ctzll(m));
-                            m &= m - 1ull;
+                    while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
+                        if (m != 0u) {
+                            S.work[w++] = (unsigned short)((lane << 8) | __builtin_ctz(m));
+                            m &= m - 1u;
+                        }
+                    }
+                    if (S.nc > 32) {
+                        m = mhi;
+                        while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
+                            if (m != 0u) {
+                                S.work[w++] = (unsigned short)((lane << 8) | (32 + __builtin_ctz(m)));
+                                m &= m - 1u;
+                            }
                         }
                     }
                 }
@@ -552,7 +575,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                     tally.add(TALLY_GROUPS, (unsigned)K4);
                     tally.add(TALLY_SPHERE_TESTS, (unsigned)(K4 * n));
                     for (int i = 0; i < K4; ++i) {
-                        const int p = S.nu4 + (k * K4 + i) * 4 + sub * n;  // per-lane LDS gather
+                        const int p = S.nu4 + (__mul24(k, K4) + i) * 4 + sub * n;  // per-lane LDS gather
                         const Cand k0 = part1(S.v[p], ro, rd, on);
                         Cand k1 = k0, k2 = k0, k3 = k0;
                         unsigned m = k0.c ? 1u : 0u;
@@ -571,6 +594,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                 const unsigned long long r = S.res[lane];
                 if (r != ~0ull) hit_unkey(r, best, bp);
             } else if (total > WORK_MAX) {  // pathological: per-lane loop over own candidates
+                unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
                 while (__builtin_amdgcn_ballot_w64(mask != 0ull) != 0ull) {
                     const bool on = mask != 0ull;
                     const int k = on ? __builtin_ctzll(mask) : 0;
@@ -578,7 +602,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                     tally.add(TALLY_GROUPS, (unsigned)K4);
                     tally.add(TALLY_SPHERE_TESTS, (unsigned)(K4 * 4));
                     for (int i = 0; i < K4; ++i) {
-                        const int p = S.nu4 + (k * K4 + i) * 4;
+                        const int p = S.nu4 + (__mul24(k, K4) + i) * 4;
                         const float4 s0 = S.v[p], s1 = S.v[p + 1], s2 = S.v[p + 2], s3 = S.v[p + 3];
                         test4c(s0, s1, s2, s3, p, o, d, on, best, bp);
                     }
@@ -1517,7 +1541,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 bool ready = false;
                 float4 e = make_float4(0, 0, 0, 0);
                 if (own_done < count) {
-                    e = ring[ring_row(own_done) * n_hit + lane];
+                    e = ring[__umul24(ring_row(own_done), (unsigned)n_hit) + (unsigned)lane];
                     ready = __float_as_uint(e.w) == own_done;
                 }
                 if constexpr (MULTI) {
@@ -1525,7 +1549,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                         bool ready_px = false;
                         float4 f = make_float4(0, 0, 0, 0);
                         if (fdone < count) {
-                            f = ring[ring_row(fdone) * n_hit + fslot];
+                            f = ring[__umul24(ring_row(fdone), (unsigned)n_hit) + (unsigned)fslot];
                             ready_px = __float_as_uint(f.w) == fdone;
                         }
                         if (__builtin_amdgcn_ballot_w64(ready | ready_px) == 0ull) break;
@@ -1718,7 +1742,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 }
                 if (end_path) {  // hand the sample colour to the slot's owner
                     const uint32_t sidx = task >> 6;
-                    ring[ring_row(sidx) * n_hit + (int)(task & 63u)] = make_float4(L.r, L.g, L.b, __uint_as_float(sidx));
+                    ring[__umul24(ring_row(sidx), (unsigned)n_hit) + (task & 63u)] = make_float4(L.r, L.g, L.b, __uint_as_float(sidx));
                     busy = false;
                 }
             }
