@@ -267,9 +267,9 @@ struct Lds {
     __device__ __forceinline__ float4 bound(int k) const { return v[off_bounds + k]; }
     __device__ __forceinline__ float4 box_c(int j) const { return v[off_box + 2 * j]; }
     __device__ __forceinline__ float4 box_h(int j) const { return v[off_box + 2 * j + 1]; }
-    // (24-bit multiplies: primitive ids are below 2^15; a plain `3 * p` became a quarter-rate 64-bit v_mad_u64_u32 per look-up)
-    __device__ __forceinline__ float4 mat(int p, int row) const { return v[off_mat + __mul24(3, p) + row]; }
-    __device__ __forceinline__ int order(int p) const { return __float_as_int(v[off_mat + __mul24(3, p) + 2].w); }
+    // (the compiler makes one v_mad_u64_u32 of `base + 48 * p`; spelled with 24-bit multiplies it was 0..1 % slower: profiles/r04/ab_notes.txt)
+    __device__ __forceinline__ float4 mat(int p, int row) const { return v[off_mat + 3 * p + row]; }
+    __device__ __forceinline__ int order(int p) const { return __float_as_int(v[off_mat + 3 * p + 2].w); }
 };
 
 // sign(float3) component (Common.hpp:328-333): t != 0 ? t / abs(t) : 0.  For finite t != 0 the quotient is exactly +-1, for
@@ -575,7 +575,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                     tally.add(TALLY_GROUPS, (unsigned)K4);
                     tally.add(TALLY_SPHERE_TESTS, (unsigned)(K4 * n));
                     for (int i = 0; i < K4; ++i) {
-                        const int p = S.nu4 + (__mul24(k, K4) + i) * 4 + sub * n;  // per-lane LDS gather
+                        const int p = S.nu4 + (k * K4 + i) * 4 + sub * n;  // per-lane LDS gather
                         const Cand k0 = part1(S.v[p], ro, rd, on);
                         Cand k1 = k0, k2 = k0, k3 = k0;
                         unsigned m = k0.c ? 1u : 0u;
@@ -602,7 +602,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                     tally.add(TALLY_GROUPS, (unsigned)K4);
                     tally.add(TALLY_SPHERE_TESTS, (unsigned)(K4 * 4));
                     for (int i = 0; i < K4; ++i) {
-                        const int p = S.nu4 + (__mul24(k, K4) + i) * 4;
+                        const int p = S.nu4 + (k * K4 + i) * 4;
                         const float4 s0 = S.v[p], s1 = S.v[p + 1], s2 = S.v[p + 2], s3 = S.v[p + 3];
                         test4c(s0, s1, s2, s3, p, o, d, on, best, bp);
                     }
@@ -1541,7 +1541,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 bool ready = false;
                 float4 e = make_float4(0, 0, 0, 0);
                 if (own_done < count) {
-                    e = ring[__umul24(ring_row(own_done), (unsigned)n_hit) + (unsigned)lane];
+                    e = ring[ring_row(own_done) * n_hit + lane];
                     ready = __float_as_uint(e.w) == own_done;
                 }
                 if constexpr (MULTI) {
@@ -1549,7 +1549,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                         bool ready_px = false;
                         float4 f = make_float4(0, 0, 0, 0);
                         if (fdone < count) {
-                            f = ring[__umul24(ring_row(fdone), (unsigned)n_hit) + (unsigned)fslot];
+                            f = ring[ring_row(fdone) * n_hit + fslot];
                             ready_px = __float_as_uint(f.w) == fdone;
                         }
                         if (__builtin_amdgcn_ballot_w64(ready | ready_px) == 0ull) break;
@@ -1742,7 +1742,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 }
                 if (end_path) {  // hand the sample colour to the slot's owner
                     const uint32_t sidx = task >> 6;
-                    ring[__umul24(ring_row(sidx), (unsigned)n_hit) + (task & 63u)] = make_float4(L.r, L.g, L.b, __uint_as_float(sidx));
+                    ring[ring_row(sidx) * n_hit + (int)(task & 63u)] = make_float4(L.r, L.g, L.b, __uint_as_float(sidx));
                     busy = false;
                 }
             }
