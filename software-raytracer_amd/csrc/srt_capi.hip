@@ -343,11 +343,13 @@ static int set_scene_impl(srt_context* ctx, const srt_object* objects, size_t co
             return fail(ctx, SRT_ERR_INVALID_ARG, "srt_set_scene: %zu objects (%d sphere slots + %d boxes + %d meshes) exceed the 32767-object limit",
                         count, L.nsT, L.nb, L.nm);
         // an image that does not fit into LDS next to the per-wave scratch stays in HBM (slower kernel
-        // instantiation, same bits); the pick kernel runs one wave, so it is judged separately
+        // instantiation, same bits); the pick kernel runs one wave, so it is judged separately.  The LDS instantiations also
+        // take the square root of the sphere test in its short form (sqrt_window, srt_kernel.hip.h), which needs every r*r in
+        // [2^-72, FLT_MAX]: a scene with a sphere outside that window runs the instantiations that keep the library sqrtf.
         const size_t image_bytes = (size_t)L.total_vec4 * sizeof(float4);
         const size_t mesh_scratch = has_mesh ? (size_t)(srt::WG_MESH_SCRATCH_BYTES) : 0;
-        ctx->scene_in_lds[v] = image_bytes + (size_t)srt::WG_SCRATCH_BYTES + mesh_scratch <= (size_t)ctx->lds_limit_bytes;
-        ctx->pick_in_lds[v] = image_bytes + srt::WAVE_SCRATCH_BYTES + srt::MESH_WAVE_BYTES <= (size_t)ctx->lds_limit_bytes;
+        ctx->scene_in_lds[v] = L.radii_in_sqrt_window && image_bytes + (size_t)srt::WG_SCRATCH_BYTES + mesh_scratch <= (size_t)ctx->lds_limit_bytes;
+        ctx->pick_in_lds[v] = L.radii_in_sqrt_window && image_bytes + srt::WAVE_SCRATCH_BYTES + srt::MESH_WAVE_BYTES <= (size_t)ctx->lds_limit_bytes;
         if (ctx->h_scene[v].size() > ctx->scene_capacity_vec4[v] || !ctx->d_scene[v]) {
             if (ctx->d_scene[v]) SRT_HIP(ctx, hipFree(ctx->d_scene[v]));
             ctx->d_scene[v] = nullptr;
@@ -1225,7 +1227,7 @@ int srt_selftest_arith(int device, uint32_t seed, uint64_t vectors, uint64_t* mi
     if (e == hipSuccess) e = hipMemset(d, 0, sizeof *d);
     for (uint64_t done = 0; e == hipSuccess && done < vectors; done += 1ull << 28) {  // grids of at most 2^20 blocks
         const uint64_t part = vectors - done < (1ull << 28) ? vectors - done : (1ull << 28);
-        hipLaunchKernelGGL(srt::selftest_normalize_kernel, dim3((unsigned)((part + 255) / 256)), dim3(256), 0, 0, seed + (uint32_t)(done >> 28) * 0x85EBCA6Bu, part, d);
+        hipLaunchKernelGGL(srt::selftest_normalize_kernel, dim3((unsigned)((part + 255) / 256)), dim3(256), 0, 0, seed + (uint32_t)(done >> 28) * 0x85EBCA6Bu, (unsigned long long)done, part, d);
         e = hipGetLastError();
     }
     unsigned long long h = 0;

@@ -215,6 +215,25 @@ __device__ __forceinline__ float div_window(float n, float d) {
     return __builtin_fmaf(__builtin_fmaf(-d, q1, n), r1, q1);
 }
 
+// sqrtf(x), correctly rounded, for x INSIDE the window in which the library expansion's rescaling and class test are identities:
+// x = +0, x NaN, or 2^-96 <= x < inf (the library scales arguments below 2^-96 by 2^32 and the root by 2^-16, and hands +-0 and
+// +inf back through v_cmp_class).  What is left: v_sqrt_f32 and the two one-ulp corrections — each neighbour's residual with one
+// FMA — ten instructions instead of seventeen and five hazard no-ops.  For x = +0 the corrections keep 0 (the lower neighbour of 0
+// is a NaN bit pattern, its residual a NaN, the compare false; the upper neighbour's residual is 0, not above 0); a NaN goes
+// through unchanged in both forms.  The one call site is the sphere test's  tc - sqrt(r*r - d2)  for a candidate (d2 <= r*r): if
+// r*r >= 2^-72 the difference of the two floats is 0 or at least 2^-96 (b <= a/2: a - b >= a/2; else Sterbenz: exact, a
+// multiple of ulp(b) >= 2^-96) — srt_set_scene checks every sphere's r*r against [2^-72, FLT_MAX] and sends a scene with a
+// sphere outside it to the instantiations that read the scene from memory, which keep the library sqrtf (SCENE_LDS == false).
+// srt_selftest_arith compares the two forms on the device.
+__device__ __forceinline__ float sqrt_window(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+    s = (0.0f >= rm) ? sm : s;
+    s = (0.0f < rp) ? sp : s;
+    return s;
+}
+
 struct V3 {
     float x, y, z;
 };
@@ -405,7 +424,7 @@ __device__ __forceinline__ void hit_unkey(unsigned long long k, float& t, int& p
 //      fetch the ray with __shfl, run the EXACT sphere arithmetic and merge through a 64-bit
 //      LDS atomicMin on hit_key — so the wave does sum(pairs)/64 rounds, not max-per-lane.
 //   3. boxes: every lane, exact arithmetic.
-template <bool MESH, bool TALLY = false>
+template <bool MESH, bool TALLY = false, bool SHORT_SQRT = false>
 __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, V3 o, V3 d, bool active, int defer_min, bool& deferred, Tally<TALLY>& tally SRT_PROF_PARAM) {
     tally.add(TALLY_CALLS, 1u);
     float best = __builtin_inff();
@@ -444,7 +463,7 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             const float tc = b3 ? k3.tc : b2 ? k2.tc : b1 ? k1.tc : k0.tc;
             const float x = b3 ? k3.x : b2 ? k2.x : b1 ? k1.x : k0.x;
             const int pj = p + (b3 ? 3 : b2 ? 2 : b1 ? 1 : 0);
-            const float t1 = tc - sqrtf(x);  // :131-133 (lanes without a candidate compute on a dead value)
+            const float t1 = tc - (SHORT_SQRT ? sqrt_window(x) : sqrtf(x));  // :131-133 (lanes without a candidate compute on a dead value)
             // Raytracer.cpp:130-132; on an exact tie the earlier entry of ObjectsToRender wins
             const bool tie = c & (t1 == tb) & (pb >= 0);
             bool win = c & (t1 < tb);
@@ -1376,7 +1395,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
 
     // ---- primary hit: identical for every sample ------------------------------------
     bool parked = false;  // path pool: this lane's ray waits for a mesh phase (see closest_hit)
-    const Hit h0 = closest_hit<MESH, TALLY>(S, P, cam, dir0, true, 1, parked, tally SRT_PROF_ARG);
+    const Hit h0 = closest_hit<MESH, TALLY, SCENE_LDS>(S, P, cam, dir0, true, 1, parked, tally SRT_PROF_ARG);
 
     const bool reset = (P.flags & 1u) != 0;
     // samples of this workgroup: all of them, or chunk blockIdx.z of the launch
@@ -1714,7 +1733,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             // the scan runs in wave-uniform control flow: idle lanes help with other lanes' rays
             // (a mesh phase waits for P.mesh_defer rays (12) — but not for long (P.mesh_wait = 3 steps): where mesh rays are rare a parked ray would hold its lane
             // and, through the ring, its slot for many steps; after P.mesh_wait steps with someone parked the phase runs for whoever is there)
-            const Hit h = closest_hit<MESH, TALLY>(S, P, o, sray, busy, MESH && park_steps >= P.mesh_wait ? 1 : P.mesh_defer, parked, tally SRT_PROF_ARG);
+            const Hit h = closest_hit<MESH, TALLY, SCENE_LDS>(S, P, o, sray, busy, MESH && park_steps >= P.mesh_wait ? 1 : P.mesh_defer, parked, tally SRT_PROF_ARG);
             if constexpr (MESH) park_steps = __builtin_amdgcn_ballot_w64(busy && parked) != 0ull ? park_steps + 1 : 0;
             if (busy && !(MESH && parked)) {
                 ++rays;
@@ -1861,7 +1880,7 @@ __global__ void __launch_bounds__(256) fold_kernel(const KernelParams P, int til
 // srt_selftest_arith: vector i of the test set, normalized() against normalized_ieee(), bit for bit.  Waves 0 mod 4 draw all
 // three components from one moderate range (the short path runs), the others mix in every class of float (mostly the library
 // path, and the decision between the two is itself under test).
-__global__ void __launch_bounds__(256) selftest_normalize_kernel(uint32_t seed, unsigned long long n, unsigned long long* mismatches) {
+__global__ void __launch_bounds__(256) selftest_normalize_kernel(uint32_t seed, unsigned long long first, unsigned long long n, unsigned long long* mismatches) {
     const unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
     const unsigned wave_kind = (unsigned)((i >> 6) & 3ull);
     uint32_t h = srt_mix32(seed ^ (uint32_t)i) + (uint32_t)(i >> 32) * 0x9E3779B9U;
@@ -1902,6 +1921,23 @@ __global__ void __launch_bounds__(256) selftest_normalize_kernel(uint32_t seed, 
         const float u = div_window(sg, dn), w = sg / dn;
         same = same && (__float_as_uint(u) == __float_as_uint(w) || (u != u && w != w));  // (a NaN slope rejects every box whatever its payload)
     }
+    // sqrt_window against sqrtf inside its window: +0, NaN (any payload, either sign), every x in [2^-96, inf) — the bit pattern
+    // of vector first + i for the call's first 2^31 vectors (so 2^31 vectors cover every non-negative float), a drawn one after that
+    {
+        const unsigned long long g = first + i;  // (the launch's first vector: a call runs in grids of 2^28)
+        const uint32_t bits = g < 0x80000000ull ? (uint32_t)g : (next() & 0x7FFFFFFFu);
+        const float x = __uint_as_float(bits);
+        const bool in_window = bits == 0u || (bits >= 0x0F800000u && bits < 0x7F800000u) || bits > 0x7F800000u;
+        if (in_window) {
+            const float u = sqrt_window(x), w = sqrtf(x);
+            same = same && (__float_as_uint(u) == __float_as_uint(w) || (u != u && w != w));
+            const float xn = __uint_as_float(bits | 0x80000000u);  // negative NaNs (x is never a negative number: d2 <= r*r)
+            if (bits > 0x7F800000u) {
+                const float un = sqrt_window(xn), wn = sqrtf(xn);
+                same = same && (un != un && wn != wn);
+            }
+        }
+    }
     if (i < n && !same) atomicAdd(mismatches, 1ull);
 }
 
@@ -1924,7 +1960,7 @@ __global__ void __launch_bounds__(64) pick_kernel(const KernelParams P, int px, 
     Prof prof{};
 #endif
     Tally<false> no_tally;
-    const Hit h = closest_hit<true>(S, P, v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]), dir, true, 1, deferred, no_tally SRT_PROF_ARG);
+    const Hit h = closest_hit<true, false, SCENE_LDS>(S, P, v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]), dir, true, 1, deferred, no_tally SRT_PROF_ARG);
     if (threadIdx.x == 0) {
         out_index[0] = h.prim >= 0 ? S.order(h.prim) : -1;
         out_index[1] = __float_as_int(h.t);
@@ -1968,7 +2004,7 @@ __global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, ui
     Prof prof{};
 #endif
     Tally<false> no_tally;
-    Hit h = closest_hit<true>(S, P, v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]), sray, in_range, 1, deferred, no_tally SRT_PROF_ARG);
+    Hit h = closest_hit<true, false, SCENE_LDS>(S, P, v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]), sray, in_range, 1, deferred, no_tally SRT_PROF_ARG);
     const int first_mesh_prim = S.nsT + S.nb;
     unsigned c = in_range ? 1u : 0u;
     bool alive = in_range && h.prim >= 0 && P.max_bounces > 0 && !(P.flags & 4u);
@@ -1993,7 +2029,7 @@ __global__ void __launch_bounds__(64) block_cost_kernel(const KernelParams P, ui
             sray = normalized(v3(sr.x * (1 - tt) + refl.x * tt, sr.y * (1 - tt) + refl.y * tt, sr.z * (1 - tt) + refl.z * tt));
             o = v3(h.p.x + h.n.x * .00001f, h.p.y + h.n.y * .00001f, h.p.z + h.n.z * .00001f);
         }
-        const Hit g = closest_hit<true>(S, P, o, sray, alive, 1, deferred, no_tally SRT_PROF_ARG);
+        const Hit g = closest_hit<true, false, SCENE_LDS>(S, P, o, sray, alive, 1, deferred, no_tally SRT_PROF_ARG);
         if (alive) {
             c += g.prim >= first_mesh_prim ? SRT_MESH_ORDER_W : 1u;
             if (g.prim < 0) {

@@ -85,6 +85,9 @@ struct SceneLayout {
     // every box centre and half size is a number of magnitude below SRT_BOX_NO_NAN_BOUND (the kernel's NaN-free slab test relies on
     // it, together with the same bound on the ray's origin: see closest_hit)
     bool boxes_finite = true;
+    // every sphere's r*r is a number in [2^-72, FLT_MAX] (the kernel's short square root relies on it: sqrt_window in
+    // srt_kernel.hip.h; a radius below 1.5e-11, zero, infinite or NaN sends the scene to the instantiations that keep the library sqrtf)
+    bool radii_in_sqrt_window = true;
 };
 
 // the four environment rows of the constants block (colours through Color's clamping constructor, Common.hpp:253-262)
@@ -242,7 +245,9 @@ inline SceneLayout build_scene_image(const srt_object* objects, size_t count, bo
     };
     auto put_sphere = [&](int p, int i) {
         const srt_object& o = objects[i];
-        img[p] = make_float4(o.position[0], o.position[1], o.position[2], o.radius * o.radius);  // Object.hpp:122
+        const float r2 = o.radius * o.radius;
+        img[p] = make_float4(o.position[0], o.position[1], o.position[2], r2);  // Object.hpp:122
+        L.radii_in_sqrt_window = L.radii_in_sqrt_window && r2 >= 0x1p-72f && r2 <= 3.402823466e+38f;  // (NaN: false)
         put_material(p, i);
     };
     for (size_t k = 0; k < uni.size(); ++k) put_sphere((int)k, uni[k]);

@@ -17,6 +17,15 @@ def test_short_normalize_equals_library_normalize(srt, seed):
     assert bad.value == 0
 
 
+def test_short_square_root_equals_library_square_root_for_every_float_in_its_window(srt):
+    """2^31 vectors: vector i also puts the float with bit pattern i through sqrt_window and sqrtf, if it lies in the window
+    (+0, [2^-96, inf), NaNs) — every non-negative float there is."""
+    L = srt.load_library()
+    bad = C.c_uint64(123)
+    assert L.srt_selftest_arith(0, 7, 1 << 31, C.byref(bad)) == 0
+    assert bad.value == 0
+
+
 def test_selftest_argument_checks(srt):
     L = srt.load_library()
     bad = C.c_uint64(0)
