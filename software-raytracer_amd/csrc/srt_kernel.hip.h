@@ -269,6 +269,23 @@ __device__ __forceinline__ V3 normalized(V3 a) {
     };
     return v3(quot(a.x), quot(a.y), quot(a.z));
 }
+// normalized() for a vector that is inside the window BY CONSTRUCTION: no test, no library path.  The one caller is the random
+// direction of GetRandomDirection (Raytracer.cpp:90-97): its components are (r / 32767 - 0.5) * 2 for an integer r in [0, 32767] —
+// never zero (r / 32767 = 0.5 has no integer solution; the nearest, r = 16383 and 16384, give -+3.05e-5 after an exact
+// subtraction and an exact doubling) and at most 1 in size: squared length in [2.8e-9, 3], every component at least 1.7e-5 of the
+// length.  The same chain as normalized()'s short path, i.e. the library's operations on the same values.
+__device__ __forceinline__ V3 normalized_in_window(V3 a) {
+    const float x = (a.x * a.x + a.y * a.y) + a.z * a.z;
+    const float len = sqrt_window(x);
+    const float r0 = __builtin_amdgcn_rcpf(len);
+    const float r1 = __builtin_fmaf(__builtin_fmaf(-len, r0, 1.0f), r0, r0);
+    auto quot = [&](float n) {
+        const float q0 = n * r1;
+        const float q1 = __builtin_fmaf(__builtin_fmaf(-len, q0, n), r1, q0);
+        return __builtin_fmaf(__builtin_fmaf(-len, q1, n), r1, q1);
+    };
+    return v3(quot(a.x), quot(a.y), quot(a.z));
+}
 __device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 
 
@@ -1116,7 +1133,9 @@ __device__ __forceinline__ RGB environment(const Lds& S, V3 d) {
     RGB Ground{e2.x, e2.y, e2.z};
     float upd = (d.x * 0.0f + d.y * 1.0f) + d.z * 0.0f;  // Dot(rayDirection, WORLDUP) :78
     float sd = (d.x * (e3.x * -1) + d.y * (e3.y * -1)) + d.z * (e3.z * -1);
-    bool sunny = (double)sd > 0.99;  // :79 float vs double literal
+    // :79 compares the float with the DOUBLE literal 0.99, which lies between the floats 0x3F7D70A3 (0.98999995) and 0x3F7D70A4
+    // (0.99000001): (double)sd > 0.99 exactly when sd >= 0x3F7D70A4 (a NaN fails both) — one float compare, no conversion
+    bool sunny = sd >= __uint_as_float(0x3F7D70A4u);
     RGB Sun{sunny ? e0.w : 0.0f, sunny ? e1.w : 0.0f, sunny ? e2.w : 0.0f};
     // one srt_powf call site for both branches (:81 powf(upd, 0.1f) / :87 powf(|upd|, .05f)):
     // the arguments are selected per lane, so up- and down-going lanes do not serialize.
@@ -1722,7 +1741,7 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 rng += 3u * 0x9E3779B9U;
                 V3 sr = v3((rand_unit(r0) - 0.5f) * 2, (rand_unit(r1) - 0.5f) * 2,
                            (rand_unit(r2) - 0.5f) * 2);
-                sr = normalized(sr);
+                sr = normalized_in_window(sr);  // (inside normalized()'s window by construction: see there)
                 if (dot3(sr, hn) < 0) sr = v3(sr.x * -1, sr.y * -1, sr.z * -1);
                 // float3::Lerp(sray, reflectedRay, Smoothness * specularProb)  (:175)
                 float tt = S.mat(hprim, 0).x * spec;
