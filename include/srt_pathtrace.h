@@ -286,7 +286,8 @@ int srt_estimate_row_costs(srt_context* ctx, int max_bounces, uint32_t seed, flo
  * accumulation weight 1 / frame without the rescaling and fix-up steps of the library sqrt / divide where those are
  * identities): `vectors` pseudo-random vectors — all magnitudes, zero and denormal components, infinities, NaNs — through
  * the short and the library path on the device, and 1 / frame for every frame up to 2^24 (vectors >= 2^24 covers them
- * all); the sphere test's short square root against sqrtf for the bit pattern of every vector index below 2^31 that lies in
+ * all); the random direction's normalization without its window test on triples of draws (the 64 extreme combinations, then random
+ * ones); the sphere test's short square root against sqrtf for the bit pattern of every vector index below 2^31 that lies in
  * its window (vectors >= 2^31 covers every float there); *mismatches = how many differ in any bit (must be 0).  Not part of the
  * reference's interface. */
 int srt_selftest_arith(int device, uint32_t seed, uint64_t vectors, uint64_t* mismatches);

@@ -1940,6 +1940,18 @@ __global__ void __launch_bounds__(256) selftest_normalize_kernel(uint32_t seed, 
         const float u = div_window(sg, dn), w = sg / dn;
         same = same && (__float_as_uint(u) == __float_as_uint(w) || (u != u && w != w));  // (a NaN slope rejects every box whatever its payload)
     }
+    // normalized_in_window on what its one caller feeds it — three draws of [0, 32767] through rand_unit, (r - 0.5) * 2 — against the
+    // library path: the 64 combinations of the extreme and the two middle draws first, random triples after that
+    {
+        const unsigned long long g = first + i;
+        const uint32_t edge[4] = {0u, 16383u, 16384u, 32767u};
+        const uint32_t hh = next();
+        const uint32_t r0 = g < 64ull ? edge[g & 3ull] : (hh & 32767u), r1 = g < 64ull ? edge[(g >> 2) & 3ull] : ((hh >> 15) & 32767u),
+                       r2 = g < 64ull ? edge[(g >> 4) & 3ull] : (next() & 32767u);
+        const V3 sr = v3((rand_unit(r0) - 0.5f) * 2, (rand_unit(r1) - 0.5f) * 2, (rand_unit(r2) - 0.5f) * 2);
+        const V3 u = normalized_in_window(sr), w = normalized_ieee(sr);
+        same = same && __float_as_uint(u.x) == __float_as_uint(w.x) && __float_as_uint(u.y) == __float_as_uint(w.y) && __float_as_uint(u.z) == __float_as_uint(w.z);
+    }
     // sqrt_window against sqrtf inside its window: +0, NaN (any payload, either sign), every x in [2^-96, inf) — the bit pattern
     // of vector first + i for the call's first 2^31 vectors (so 2^31 vectors cover every non-negative float), a drawn one after that
     {
