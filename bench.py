@@ -63,7 +63,7 @@ BAND_ALIGN = 2                             # rows: boundaries of the cost-balanc
 # `step` is calibrated ONCE on config 2, `bvh_round` and `mesh_phase` on config 4: (SQ_INSTS_VALU - the priced tests) / the count,
 # from profiles/r04/pmc_c2.json and pmc_c4.json; profiles/r04/valu_model.json checks the model against the instruction counter of
 # every other workload.
-VALU_MODEL = {"sphere": 24, "box": 35, "triangle": 40, "bound": 14, "bvh_child": 21, "step": 800, "bvh_round": 240, "mesh_phase": 300, "sample": 30}
+VALU_MODEL = {"sphere": 24, "box": 35, "triangle": 40, "bound": 14, "bvh_child": 21, "step": 780, "bvh_round": 240, "mesh_phase": 300, "sample": 30}
 
 # BASELINE.json configs, 1-based.  mesh = tessellation of Scene1's big ball (224 -> 99,904 triangles)
 CONFIGS = {
