@@ -484,7 +484,9 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
             // Raytracer.cpp:130-132; on an exact tie the earlier entry of ObjectsToRender wins
             const bool tie = c & (t1 == tb) & (pb >= 0);
             bool win = c & (t1 < tb);
-            if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // rare: only then are the list indices needed (two LDS reads)
+            // rare: only then are the list indices needed (two LDS reads).  (The ballot of the bare compare — a superset of `tie` — is the
+            // compare's own scalar result; the ballot of a combined predicate costs a select and a compare more.)
+            if (__builtin_amdgcn_ballot_w64(t1 == tb) != 0ull) {
                 const int op = S.order(pj), ob = S.order(tie ? pb : pj);
                 win = win | (tie & (op < ob));
             }
@@ -675,10 +677,10 @@ __device__ __forceinline__ Hit closest_hit(const Lds& S, const KernelParams& P, 
                 V3 t1;
                 float dist = ibox_dist<decltype(tag)::value>(br, v3(o.x - c.x, o.y - c.y, o.z - c.z), v3(hs.x, hs.y, hs.z), t1);
                 bool valid = active && dist != 3.402823466e+38f;  // Object.hpp:231
-                if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
+                if (__builtin_amdgcn_ballot_w64(dist != 3.402823466e+38f) != 0ull) {  // (bare compares: see `candidates`; supersets of valid / tie)
                     const bool tie = valid & (dist == best) & (bp >= 0);
                     bool win = valid & (dist < best);
-                    if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // rare: list indices only on an exact tie
+                    if (__builtin_amdgcn_ballot_w64(dist == best) != 0ull) {  // rare: list indices only on an exact tie
                         const int ob = S.order(tie ? bp : nsT + j);
                         win = win | (tie & (S.order(nsT + j) < ob));
                     }
