@@ -154,6 +154,8 @@ def main():
             print(name, "final bench failed:", r.stderr[-500:])
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import profile_check as PC
+    import valu_per_step  # VALU instructions per pool step / per traced ray into every pmc_<name>.json (`derived`)
+    valu_per_step.derive(out)
     probs = PC.check_round(out)
     print("profile_check: %s" % ("all workloads describe the same launches" if not probs else "\n  ".join(["PROBLEMS"] + probs)), flush=True)
 
