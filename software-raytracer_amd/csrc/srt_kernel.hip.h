@@ -1723,6 +1723,12 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                 SRT_STAT(6, n_hit);
             }
 #endif
+#if defined(SRT_STATS) && SRT_STATS == 9  // make dev STATS=9: pool steps by the number of lanes on a live path (tests/pool_stats.py --histogram)
+            {
+                const int nb_ = __builtin_popcountll(__builtin_amdgcn_ballot_w64(busy));
+                SRT_STAT(nb_ <= 8 ? 0 : nb_ <= 16 ? 1 : nb_ <= 32 ? 2 : nb_ <= 48 ? 3 : nb_ <= 56 ? 4 : nb_ <= 60 ? 5 : nb_ <= 63 ? 6 : 7, 1);
+            }
+#endif
             tally.add(TALLY_STEPS, 1u);
             // ---- one bounce for every busy lane
             V3 o = v3(0, 0, 0);

@@ -12,9 +12,10 @@ ap.add_argument("--mesh", type=int, default=0)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--rows", default="")
+ap.add_argument("--histogram", action="store_true", help="STATS=9 build: pool steps by the number of lanes on a live path")
 a = ap.parse_args()
 srt = importlib.import_module("software-raytracer_amd")
-srt.capi.use_dev_library(stats=4)
+srt.capi.use_dev_library(stats=9 if a.histogram else 4)
 L = srt.load_library()
 path = os.path.join(ROOT, "software-raytracer_amd", "scenes", a.scene + ".json")
 if a.mesh:
@@ -30,6 +31,12 @@ out = (C.c_ulonglong * 8)()
 for _ in range(3):
     pt.render(spp=a.spp, bounces=a.bounces, seed=0, count_rays=True, rows=rows); st = pt.stats(); L.srt_debug_read_stats(out)
 o = list(out)
+if a.histogram:
+    tot = max(sum(o), 1)
+    names = ["1-8", "9-16", "17-32", "33-48", "49-56", "57-60", "61-63", "64"]
+    print("%s%s spp %d rows %s: %d pool steps by lanes on a live path: %s" % (a.scene, "+mesh" if a.mesh else "", a.spp, a.rows or "all", tot,
+          "  ".join("%s: %.1f %%" % (n, 100.0 * v / tot) for n, v in zip(names, o))))
+    sys.exit(0)
 steps = max(o[0], 1)
 print("%s%s spp %d rows %s: kernel %.3f ms (with counters), %d sample chunks, rays %d" % (a.scene, "+mesh" if a.mesh else "", a.spp, a.rows or "all", st.kernel_ms, st.sample_chunks, st.rays))
 print("  pool steps %d, busy lanes per step %.1f of 64, traced pixels per tile (step-weighted) %.1f" % (o[0], o[1] / steps, o[6] / steps))
