@@ -46,6 +46,7 @@ struct DevSwitches {
     int chunk_beta = 30;   // SRT_CHUNK_BETA (percent): sample chunks from recorded block costs, see srt_render
     bool host_order = true;  // SRT_HOST_ORDER=0: no host-derived initial dispatch order
     int kernel_flags = 0;    // SRT_KFLAGS: extra KernelParams.flags bits of timing experiments
+    bool chain = true;       // SRT_CHAIN=0: every chunk of a sample-chunked launch goes through the sample buffer (round 3's form)
 };
 #ifdef SRT_DEV
 const DevSwitches& dev_switches() {
@@ -65,6 +66,7 @@ const DevSwitches& dev_switches() {
         d.chunk_beta = geti("SRT_CHUNK_BETA", 30);
         d.host_order = geti("SRT_HOST_ORDER", 1) != 0;
         d.kernel_flags = geti("SRT_KFLAGS", 0);
+        d.chain = geti("SRT_CHAIN", 1) != 0;
         return d;
     }();
     return sw;
@@ -123,6 +125,7 @@ struct srt_context {
     size_t samples_capacity = 0;  // bytes
     unsigned long long* d_tile_masks = nullptr;
     size_t tile_masks_capacity = 0;  // entries
+    uint32_t* d_tile_chain = nullptr;  // sample-chunked launches: chunks of a tile folded in order so far (KernelParams.tile_chain), same capacity
 
     // cost-ordered dispatch: a launch may record the ray count of every block of tiles; once that copy has
     // arrived (polled, never waited for) later launches of the same grid start the expensive blocks first
@@ -306,6 +309,7 @@ int srt_destroy(srt_context* ctx) {
     if (ctx->ev_gather) (void)hipEventDestroy(ctx->ev_gather);
     if (ctx->ev_read) (void)hipEventDestroy(ctx->ev_read);
     if (ctx->d_tile_masks) (void)hipFree(ctx->d_tile_masks);
+    if (ctx->d_tile_chain) (void)hipFree(ctx->d_tile_chain);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -769,10 +773,15 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
         }
         if (ok && tiles > ctx->tile_masks_capacity) {
             if (ctx->d_tile_masks) (void)hipFree(ctx->d_tile_masks);
+            if (ctx->d_tile_chain) (void)hipFree(ctx->d_tile_chain);
             ctx->d_tile_masks = nullptr;
+            ctx->d_tile_chain = nullptr;
             ctx->tile_masks_capacity = 0;
-            if (hipMalloc((void**)&ctx->d_tile_masks, tiles * sizeof(unsigned long long)) == hipSuccess) ctx->tile_masks_capacity = tiles;
-            else ok = false, (void)hipGetLastError();
+            if (hipMalloc((void**)&ctx->d_tile_masks, tiles * sizeof(unsigned long long)) == hipSuccess &&
+                hipMalloc((void**)&ctx->d_tile_chain, tiles * sizeof(uint32_t)) == hipSuccess)
+                ctx->tile_masks_capacity = tiles;
+            else
+                ok = false, (void)hipGetLastError();
         }
         if (!ok) srt::shape_without_sample_buffer(shape);  // no room for the sample buffer: small tiles instead
     }
@@ -785,6 +794,11 @@ int srt_render(srt_context* ctx, const srt_render_params* p) {
     K.chunk_full = shape.chunk_full;
     K.sample_rows = ctx->d_samples;
     K.tile_masks = ctx->d_tile_masks;
+    // chained chunks: a chunk that finds its tile's running mean at its own first sample folds its samples itself (srt_kernel.hip.h,
+    // KernelParams.tile_chain); the counts start at zero
+    K.tile_chain = defer && dev_switches().chain ? ctx->d_tile_chain : nullptr;
+    K.chunk_layers = chunks;
+    if (K.tile_chain) SRT_HIP(ctx, hipMemsetAsync(K.tile_chain, 0, (size_t)wg8 * srt::WG_TILES_X * srt::WG_TILES_Y * sizeof(uint32_t), ctx->stream));
     dim3 grid((unsigned)wg_x, (unsigned)((grid_h + tile_h * srt::WG_TILES_Y - 1) / (tile_h * srt::WG_TILES_Y)), (unsigned)chunks);
     dim3 block(srt::WG_THREADS);
     // Cost-ordered dispatch.  The hardware starts workgroups in linear order; with the natural order the

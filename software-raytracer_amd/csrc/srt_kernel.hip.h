@@ -97,6 +97,13 @@ struct KernelParams {
     int32_t chunk_full;      // grid layers z < chunk_full trace `chunk` samples each, the layers behind them half as many (the launch's tail)
     float4* sample_rows;     // [tile][sample][64 slots] sample colours
     unsigned long long* tile_masks;  // [tile] which pixels of the tile are traced (slot k = k-th set bit)
+    // chained chunks (round 4): [tile] how many of the tile's chunks have been folded IN ORDER straight into the accumulator by
+    // the workgroups that traced them (zeroed by the host before the launch; NULL: every chunk goes through the sample buffer).
+    // Chunk z of a tile folds its own samples if it finds z here when it starts — chunk z - 1 has stored the running mean — and
+    // raises the count when it is done; otherwise it stores its colours as rows of the sample buffer, like every chunk behind it,
+    // and fold_kernel picks the tile up from the count.  No workgroup ever waits for another.
+    uint32_t* tile_chain;
+    int32_t chunk_layers;    // grid layers of the launch (fold_kernel: where a tile's chain may stand)
     // cost-ordered dispatch: workgroup i of the launch works on tile block wg_order[i] (NULL: i); every
     // wave adds its run time (10 ns ticks of the constant clock) to wg_cost[block] (NULL: not recorded) for the order of the next launch
     const uint32_t* wg_order;
@@ -402,6 +409,21 @@ struct Tally<true> {
     __device__ __forceinline__ void add(int i, unsigned x) { v += lane == (unsigned)i ? x : 0u; }
     __device__ __forceinline__ unsigned get(int i) const { return (unsigned)__builtin_amdgcn_readlane((int)v, i); }
 };
+
+// Loads and stores that are coherent across the GPU's XCDs without a fence (relaxed atomics at agent scope: gfx950 sets sc1 on
+// them, they are served by the memory side of the L2s).  The chained chunks order them with the counters' own completion — the
+// producer waits for its stores (s_waitcnt vmcnt(0)) before it raises the tile's count, the consumer's loads depend on the count
+// it read — so neither side needs the whole-L2 write-back / invalidate an acquire or release fence at agent scope would bring.
+__device__ __forceinline__ uint32_t coherent_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coherent_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float4 coherent_load(const float4* p) {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+    return make_float4(__uint_as_float(coherent_load(q)), __uint_as_float(coherent_load(q + 1)), __uint_as_float(coherent_load(q + 2)), __uint_as_float(coherent_load(q + 3)));
+}
+__device__ __forceinline__ void coherent_store(float4* p, const float4 v) {
+    uint32_t* q = reinterpret_cast<uint32_t*>(p);
+    coherent_store(q, __float_as_uint(v.x)), coherent_store(q + 1, __float_as_uint(v.y)), coherent_store(q + 2, __float_as_uint(v.z)), coherent_store(q + 3, __float_as_uint(v.w));
+}
 
 struct Hit {
     float t;   // distance of the recorded hit
@@ -1547,6 +1569,15 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
             own_pixel = __float_as_uint(rec[lane * 12 + 11]);
             if (!DEFER && !reset && !bgrid) acc = P.accumulator[own_pixel];
         }
+        // chained chunks (KernelParams.tile_chain): does this tile's running mean stand at this chunk's first sample?
+        bool chained = false;  // (wave-uniform)
+        if constexpr (DEFER) {
+            if (P.tile_chain) {
+                const uint32_t at = blockIdx.z == 0 ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)coherent_load(P.tile_chain + tile_id));
+                chained = at == blockIdx.z;
+                if (chained && owner && (blockIdx.z > 0 || !reset)) acc = coherent_load(P.accumulator + own_pixel);
+            }
+        }
 
         // path state of the task this lane is running
         bool busy = false;
@@ -1616,7 +1647,9 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
                     __builtin_amdgcn_ballot_w64(own_next < count && own_next >= own_done + (uint32_t)depth) == 0ull)
                     break;
                 if (ready) {
-                    if constexpr (DEFER)  // row (tile, sample) of the sample buffer: 64 slots of 16 B, coalesced
+                    if (DEFER && chained)  // this chunk is the tile's next one: straight into the running mean
+                        accumulate(acc, RGB{e.x, e.y, e.z}, s_base + own_done);
+                    else if constexpr (DEFER)  // row (tile, sample) of the sample buffer: 64 slots of 16 B, coalesced
                         P.sample_rows[(tile_id * P.sample_count + s_base + own_done) * 64 + lane] = e;
                     else if (MULTI && bgrid_keep)
                         acc = e;
@@ -1802,6 +1835,16 @@ __global__ void __launch_bounds__(WG_THREADS, MIN_WAVES) pathtrace_kernel(const 
         } else if (!DEFER && !PROBE && owner) {
             write_pixel(own_pixel, acc);
         }
+        if constexpr (DEFER) {
+            if (chained) {  // the running mean goes back — with the pixel, if this was the tile's last chunk — and the tile's count goes up
+                if (owner) {
+                    if (blockIdx.z + 1 == gridDim.z) write_pixel(own_pixel, acc);
+                    else coherent_store(P.accumulator + own_pixel, acc);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every lane's stores have completed
+                if (lane == 0) coherent_store(P.tile_chain + tile_id, (uint32_t)blockIdx.z + 1u);
+            }
+        }
     }
 
 #if defined(SRT_STATS) && SRT_STATS == 3
@@ -1882,14 +1925,22 @@ __global__ void __launch_bounds__(256) fold_kernel(const KernelParams P, int til
     const int x = bx * WG_W + (bit & (TILE_W - 1)) * WG_TILES_X + (wave % WG_TILES_X);  // (pathtrace_kernel's pixel-to-wave dealing)
     const int y = P.y0 + by * WG_H + (bit / TILE_W) * WG_TILES_Y + (wave / WG_TILES_X);
     const uint32_t pixel = (uint32_t)(x + y * P.width);
-    float4 acc = (P.flags & 1u) ? make_float4(0, 0, 0, 0) : P.accumulator[pixel];
+    // chained chunks: the tile's first `at` chunks were folded by the workgroups that traced them (KernelParams.tile_chain)
+    uint32_t first = 0u;
+    if (P.tile_chain) {
+        const uint32_t at = P.tile_chain[tile_id];
+        if (at >= (uint32_t)P.chunk_layers) return;  // all of them: the last one stored the pixel
+        const uint32_t zf = (uint32_t)P.chunk_full, S = (uint32_t)P.chunk, half = S >> 1;
+        first = at < zf ? at * S : zf * S + (at - zf) * half;  // (pathtrace_kernel's s_base)
+    }
+    float4 acc = ((P.flags & 1u) && first == 0u) ? make_float4(0, 0, 0, 0) : P.accumulator[pixel];
     // (Round 3 tried the layout [tile][group of 8 samples][slot][8 samples] — a 128-byte line = 8 consecutive samples of ONE slot,
     // written by one lane — to get the sample buffer's lines to memory in one piece: WRITE_SIZE of config 3's floor band stayed at
     // 2.6x the bytes stored (5.5 GB for 2.1 GB: a line's eight 16-byte writes are many steps apart in either layout, longer than
     // 512 waves' open lines stay in an XCD's 4 MB L2), and this kernel's strided reads made the middle band 5 % slower.)
     const float4* row = P.sample_rows + tile_id * P.sample_count * 64 + lane;
     const uint32_t n = P.sample_count;
-    uint32_t s = 0;
+    uint32_t s = first;
     for (; s + 8 <= n; s += 8) {  // eight loads in flight per lane
         float4 c[8];
 #pragma unroll
