@@ -506,7 +506,7 @@ def main():
         bruteforce_valu = sum(rank_bf) / (slowest_ms * 1e-3)
         peak_valu = VALU_PEAK_LANEOPS * len(per_rank)
         abytes = algorithmic_bytes(W, re - rb, n_obj, resume=False)
-        abytes += 32 * traced_samples  # sample-chunked launch: + 16 B written and 16 B read per traced sample (the fold's stream)
+        abytes += 32 * traced_samples  # sample-chunked launch: + 16 B written and 16 B read per traced sample (the fold's stream; an upper figure since the chained chunks)
         achieved_gbs = abytes / (k_ms * 1e-3) / 1e9
         kind = ("executed lane-ops COUNTED by this run (one untimed launch of the same shape with SRT_RENDER_COUNT_WORK; `counted`) priced with "
                 "`valu_model`: tests x the SURVEY §8d constants + the stated per-bound / per-BVH-child / per-step figures (DESIGN.md §4.7)")
@@ -600,7 +600,9 @@ def main():
                 "traffic": counters.get("hbm_bytes_per_launch"),
                 "algorithmic_bytes_per_launch": abytes,
                 "note": "compulsory bytes only (20 B/pixel + scene%s); not the limiting resource" %
-                        (" + 32 B per traced sample of the chunked launch's sample buffer" if chunks > 1 else ""),
+                        (" + 32 B per traced sample of the chunked launch's sample buffer — what the launch moves if every chunk goes through the buffer; chunks that "
+                         "find their tile's running mean at their own first sample fold their samples themselves (chained chunks, DESIGN.md §4.5), so `traffic` can come out "
+                         "BELOW this figure" if chunks > 1 else ""),
             },
             "per_rank": [{"kernel_ms": p[0], "gather_ms": p[4] if world > 1 else None, "rays_per_sample": p[1] / p[2], "rows": list(rank_rows[i]),
                           "executed_laneops": rank_ex[i], "frac": rank_ex[i] / (p[0] * 1e-3) / VALU_PEAK_LANEOPS, "pool_steps": p[5],
