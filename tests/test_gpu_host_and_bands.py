@@ -440,3 +440,37 @@ def test_poll_while_busy_then_render_again(srt):
     pt.render(spp=1, bounces=8, seed=0)
     assert np.array_equal(pt.framebuffer(), a)
     pt.close()
+
+
+@pytest.mark.parametrize("name,rows,spp,mesh", [("Scene1", (945, 1080), 256, 0), ("Scene1", (540, 675), 384, 0), ("Scene3", (400, 540), 256, 0)])
+def test_a_sample_chunked_launch_equals_the_same_samples_in_small_launches(srt, name, rows, spp, mesh):
+    """Chained chunks: in a sample-chunked launch a chunk folds its own samples when it finds its tile's running
+    mean at its own first sample, and stores them for fold_kernel otherwise — which of the two depends on when the workgroups
+    happen to run (on a grid that barely fills the chip about half the tiles chain).  Whatever they did, the running mean is
+    folded in sample order: the band must come out bit for bit as from a sequence of 32-sample launches, each of which resumes
+    the frame in one piece — three times over, in fresh contexts."""
+    w, h = 1920, 1080
+    sc = srt.host.Scene(scene_path(name))
+    objs, n = sc.objects_copy()
+
+    def band(chunks_of):
+        pt = srt.PathTracer(w, h)
+        pt.set_scene(objs, n)
+        pt.set_camera(srt.default_camera())
+        done, layers = 0, []
+        while done < spp:
+            k = min(chunks_of, spp - done)
+            pt.render(spp=k, bounces=8, seed=21, first_sample=1 + done, reset=done == 0, rows=rows)
+            layers.append(int(pt.stats().sample_chunks))
+            done += k
+        fb, acc = pt.framebuffer().copy(), pt.accumulator().copy()  # (whole frames: outside the band both are untouched)
+        pt.close()
+        return fb, acc, layers
+
+    ref_fb, ref_acc, small = band(32)
+    assert max(small) <= 2  # (32 samples: one piece, or the two halves of an analytic launch)
+    for _ in range(3):
+        fb, acc, layers = band(spp)
+        assert layers[0] >= 4, layers  # a sample-chunked launch
+        assert np.array_equal(acc.view(np.uint32), ref_acc.view(np.uint32))
+        assert np.array_equal(fb, ref_fb)
