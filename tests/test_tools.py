@@ -85,3 +85,16 @@ def test_committed_profiles_describe_the_same_launches():
 
         pytest.skip("no profiles/r04+ yet")
     assert PC.check_round(rounds[-1]) == []
+
+
+def test_valu_per_step_figures_are_in_the_committed_counter_files():
+    """tools/valu_per_step.py writes `derived` into every pmc_<name>.json of a round (VALU wave-instructions per pool step, lane-
+    instructions per traced ray); config 2's carries the round's before / after history and must show the instructions going DOWN."""
+    d = os.path.join(ROOT, "profiles", "r04")
+    doc = json.load(open(os.path.join(d, "pmc_c2.json")))
+    dv = doc["derived"]
+    assert 1000 < dv["valu_wave_instructions_per_pool_step"] < 1500 and 1200 < dv["valu_lane_instructions_per_traced_ray"] < 1600
+    hist = [h["valu_wave_instructions_per_pool_step"] for h in dv["history"]] + [dv["valu_wave_instructions_per_pool_step"]]
+    assert hist == sorted(hist, reverse=True) and hist[0] > 1.1 * hist[-1]
+    for name in ("c4", "c5_rank5of8", "scene_indirect"):
+        assert "derived" in json.load(open(os.path.join(d, "pmc_%s.json" % name)))
