@@ -588,10 +588,13 @@ struct ProbeWeights {
     // where the group weight of 760 and the per-tile 5830 stood in for each other; per block a group of exact tests costs a
     // seventh of a step, profiles/r04/shape_fit.txt, and Scene3's rows differ in exactly that).  Scene2, Scene_indirect and config
     // 4's scene at 4K stay held out (profiles/emulated_ranks.json; tools/band_fit.py, profiles/r04/band_fit.txt).
-    double group = 134.0;          // four clustered spheres through the exact test for 64 items (with the scatter, shuffles and merge of its round)
-    double node_round = 27.0, leaf_trip = 200.0, mesh_phase = 64.0, node_test = 62.0;  // BVH traversal: rounds, triangle trips, phases, child boxes per lane and round
-    double wave = 80.0;            // per tile: staging, primary rays, ring — what every sample chunk of a real launch repeats
-    double untraced_wave = 74.0;   // a tile with sample-independent pixels folds their colour sample by sample
+    // Refitted once more at the end of round 4 on the final kernels (a pool step had become ~ 9 % cheaper, the exact rounds cheaper than
+    // that; same three workloads, same tool; before: group 134, node_round 27, leaf_trip 200, mesh_phase 64, node_test 62, wave 80,
+    // untraced_wave 74): mean / slowest at N = 8 0.941 / 0.934 / 0.933 on the fitted workloads, 0.962 / 0.991 / 0.927 on the held-out ones.
+    double group = 220.0;          // four clustered spheres through the exact test for 64 items (with the scatter, shuffles and merge of its round)
+    double node_round = 23.0, leaf_trip = 346.0, mesh_phase = 58.0, node_test = 63.0;  // BVH traversal: rounds, triangle trips, phases, child boxes per lane and round
+    double wave = 114.0;           // per tile: staging, primary rays, ring — what every sample chunk of a real launch repeats
+    double untraced_wave = 94.0;   // a tile with sample-independent pixels folds their colour sample by sample
 };
 static double probe_step_weight(const srt::KernelParams& K, const ProbeWeights& w) {
     return w.step + w.step_ugroup * ((K.nu + 3) / 4) + w.step_cluster * K.nc + w.step_box * K.nb + (K.n_tris > 0 ? w.step_mesh : 0.0);

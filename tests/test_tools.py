@@ -13,11 +13,11 @@ from conftest import ROOT
 def test_band_fit_reproduces_round_4s_joint_fit():
     """tools/band_fit.py on the committed emulations of configs 3 and 5 and Scene3 gives the weights the library ships."""
     d = os.path.join(ROOT, "profiles", "r04", "band_fit")
-    files = [os.path.join(d, f + ".json") for f in ("c3_w1", "c3_w2", "c5_w1", "c5_w2", "s3_w0", "s3_w1", "s3_w2", "s3_w3")]
+    files = [os.path.join(d, f + ".json") for f in ("c3_final", "c5_final", "s3_final")]  # (the round's last fit, on the final kernels)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "band_fit.py")] + files, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-1000:]
     w = json.loads(re.search(r"^weights: (\{.*\})$", out.stdout, re.M).group(1))
-    assert 100 < w["groups"] < 180 and w["waves"] < 500 and 40 < w["node_tests"] < 90, w
+    assert 180 < w["groups"] < 260 and w["waves"] < 500 and 40 < w["node_tests"] < 90, w
 
 
 def test_band_fit_runs_on_the_committed_iterations():
